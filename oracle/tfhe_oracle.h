@@ -1,0 +1,198 @@
+/*
+ * tfhe_oracle.h -- CPU ORACLE (test infrastructure, NOT the product).
+ *
+ * A literal, scalar C restatement of the bootstrapping path of the reference crate
+ * Janmajayamall/tfhe-research (Rust, `tfhe` v0.1.0).  Every function cites the reference
+ * file:line it follows.  Semantics are the reference's release-mode semantics: all words are
+ * u32 and every + - * << wraps mod 2^32.
+ *
+ * Who may use this: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, and
+ * only as the checker.  The shipped library (tfhe-research_amd/csrc) never links, loads or
+ * calls anything in oracle/.
+ *
+ * PINNING STATUS.  The reference is Rust and cannot be built in this image (no cargo/rustc), and
+ * its tests hold no golden vectors: every test draws from thread_rng().  The oracle is pinned by
+ * restating the reference's own *asserting* tests (oracle/selftest.c):
+ *   - decomposer.rs:103-115  `decomposition`   (exhaustive 10^8 loop at logB=4, l=7)
+ *   - utils.rs:265-272       `poly_mul_works`  (Toeplitz.dot == schoolbook on fixed vectors)
+ *   - utils.rs:275-305       `poly_mul_monomial_works`
+ *   - lwe.rs:183-194, glwe.rs:275-294, key_switching.rs:118-159, bootstrapping.rs:194-230,
+ *     boolean.rs:67-101      decrypt-correctness asserts
+ * and cross-checked against an independent numpy restatement (oracle/pyref.py).  Beyond those,
+ * bit-level PARITY IS UNPINNED by the reference (it offers nothing to pin against).
+ */
+#ifndef TFHE_ORACLE_H
+#define TFHE_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* decomposer.rs:2-6 */
+typedef struct {
+    uint32_t log_base;
+    uint32_t levels;
+    uint32_t log_q;
+} orc_decomposer;
+
+/* lib.rs:23-34 (field names kept; glwe_poly_degree is log2(N), see lib.rs:40,60) */
+typedef struct {
+    uint32_t glwe_dimension;   /* k */
+    uint32_t glwe_poly_degree; /* log2 N */
+    uint32_t lwe_dimension;    /* n */
+    uint32_t padding_bits;
+    uint32_t log_p;
+    uint32_t log_q;            /* must be 32: the reference is hard-typed to u32 */
+    orc_decomposer ks_decomposer;
+    orc_decomposer pbs_decomposer;
+    double lwe_std_dev;
+    double glwe_std_dev;
+} orc_params;
+
+/* 0 = ok; nonzero = the reference would panic / loop forever on these parameters */
+int orc_params_validate(const orc_params *p);
+/* lib.rs:101-123 (non-test Default) and lib.rs:77-99 (cfg(test) Default, n = 4) */
+void orc_params_default(orc_params *p, int cfg_test);
+
+/* poly_mul strategy: 0 = literal (materialise the N x N Toeplitz matrix, then mat-vec, as
+ * utils.rs:155-160 does); 1 = schoolbook negacyclic (utils.rs:221-236), same bits, no matrix. */
+void orc_set_poly_mul_mode(int mode);
+int orc_get_poly_mul_mode(void);
+
+/* ---- decomposer.rs ---- */
+uint32_t orc_round_value(const orc_decomposer *d, uint32_t value);             /* :27-40 */
+int orc_decompose(const orc_decomposer *d, uint32_t value, uint32_t *out);     /* :42-80, out[levels] MSB first */
+uint32_t orc_recompose(const orc_decomposer *d, const uint32_t *legs);         /* :83-95 */
+
+/* ---- utils.rs ---- */
+uint32_t orc_integer_division(uint32_t a, uint32_t divisor);                   /* :13-18 */
+void orc_switch_modulus(const uint32_t *values, size_t len, uint32_t log_from, uint32_t log_to,
+                        uint32_t *out);                                        /* :23-33 */
+void orc_teoplitz(const uint32_t *p, size_t n, uint32_t *matrix);              /* :113-153, n*n row-major */
+void orc_poly_mul(const uint32_t *p0, const uint32_t *p1, size_t n, uint32_t *res);  /* :155-160 */
+void orc_school_book_negacylic_mul(const uint32_t *p0, const uint32_t *p1, size_t n,
+                                   uint32_t *res);                             /* :221-236 */
+/* p0: rows x n contiguous; p1: rows polynomials, row r at p1 + r*p1_row_stride */
+void orc_poly_dot_product(const uint32_t *p0, const uint32_t *p1, size_t p1_row_stride,
+                          size_t rows, size_t n, uint32_t *res);               /* :163-173 */
+void orc_poly_mul_monomial(const uint32_t *p0, size_t n, int64_t monomial_index,
+                           uint32_t *res);                                     /* :183-207 */
+
+/* ---- glwe.rs ---- */
+void orc_glwe_mul_monomial(const uint32_t *glwe, size_t rows, size_t n, int64_t monomial_index,
+                           uint32_t *out);                                     /* :20-34 */
+void orc_glwe_add_assign(uint32_t *lhs, const uint32_t *rhs, size_t len);      /* :37-41 */
+void orc_glwe_sub_assign(uint32_t *lhs, const uint32_t *rhs, size_t len);      /* :52-56 */
+int orc_decompose_poly(const uint32_t *poly, size_t n, const orc_decomposer *d,
+                       uint32_t *out /* levels x n */);                        /* :69-85 */
+int orc_decompose_glwe_ciphertext(const uint32_t *glwe, size_t rows, size_t n,
+                                  const orc_decomposer *d,
+                                  uint32_t *out /* rows*levels x n */);        /* :90-108 */
+int orc_glwe_encode_message(const orc_params *p, const uint32_t *message, size_t len,
+                            uint32_t *out /* N */);                            /* :141-151 */
+void orc_trivial_encrypt_glwe_plaintext(const orc_params *p, const uint32_t *plaintext,
+                                        uint32_t *out /* (k+1) x N */);        /* :232-243 */
+
+/* ---- ggsw.rs ---- */
+int orc_external_product(const orc_params *p, const uint32_t *ggsw /* R x (k+1) x N */,
+                         const uint32_t *glwe, uint32_t *out);                 /* :132-161 */
+int orc_cmux(const orc_params *p, const uint32_t *ggsw, const uint32_t *ct0,
+             uint32_t *ct1 /* clobbered with ct1-ct0 */, uint32_t *out);       /* :164-178 */
+
+/* ---- bootstrapping.rs / key_switching.rs ---- */
+int orc_sample_extract(const orc_params *p, const uint32_t *glwe, size_t sample_index,
+                       uint32_t *out /* kN+1 */);                              /* bootstrapping.rs:122-156 */
+int orc_key_switch_lwe(const uint32_t *lwe, size_t from_n, size_t to_n, const orc_decomposer *d,
+                       const uint32_t *ksk /* from_n*levels x (to_n+1) */,
+                       uint32_t *out /* to_n+1 */);                            /* key_switching.rs:63-103 */
+
+/* Optional capture of every intermediate of bootstrap(); any pointer may be NULL. */
+typedef struct {
+    uint32_t *approximate_lwe;   /* n+1 */
+    uint32_t *acc_init;          /* (k+1) x N : X^{-b~} * trivial(TV') */
+    uint32_t *acc_after_each;    /* n x (k+1) x N */
+    uint32_t *acc_final;         /* (k+1) x N */
+    uint32_t *extracted_lwe;     /* kN+1 */
+} orc_bootstrap_trace;
+
+/* bootstrapping.rs:58-120.  bsk: n GGSWs contiguous [n][R][k+1][N]; ksk [kN*l_ks][n+1];
+ * test_vector_poly: N un-encoded values (< 2^log_p).  The two unused secret-key arguments of the
+ * reference signature (bootstrapping.rs:61-62) carry no information and are omitted. */
+int orc_bootstrap(const orc_params *p, const uint32_t *lwe_ct, const uint32_t *bsk,
+                  const uint32_t *ksk, const uint32_t *test_vector_poly, uint32_t *out,
+                  orc_bootstrap_trace *trace);
+/* blind rotation only (bootstrapping.rs:67-105): returns acc (k+1) x N */
+int orc_blind_rotate(const orc_params *p, const uint32_t *lwe_ct, const uint32_t *bsk,
+                     const uint32_t *test_vector_poly, uint32_t *acc_out,
+                     orc_bootstrap_trace *trace);
+
+/* ---- test_vector.rs ---- */
+int orc_construct_test_from_lut(const orc_params *p, const uint32_t *lut, size_t lut_len,
+                                uint32_t *out /* N */);                        /* :38-67 */
+int orc_construct_identity_test_vector(const orc_params *p, uint32_t *out);   /* :23-35 */
+/* truth[(l<<1)|r] = f(l, r): the closure of test_vector.rs:5-20 as a 4-entry table */
+int orc_construct_test_vector_boolean(const orc_params *p, const uint32_t truth[4],
+                                      uint32_t *out);                          /* :5-20 */
+
+/* ---- lwe.rs / boolean.rs ---- */
+void orc_lwe_add(const uint32_t *a, const uint32_t *b, size_t len, uint32_t *out);   /* lwe.rs:9-15 */
+void orc_lwe_mul_scalar(const uint32_t *a, uint32_t s, size_t len, uint32_t *out);   /* lwe.rs:17-23 */
+/* boolean.rs:9-30 / :32-53 generalised over the closure: ct_in = 2*ct1 + ct0, bootstrap */
+int orc_boolean_gate(const orc_params *p, const uint32_t truth[4], const uint32_t *ct0,
+                     const uint32_t *ct1, const uint32_t *bsk, const uint32_t *ksk,
+                     uint32_t *out);
+
+/* ================= host-side crypto (keygen / encrypt / decrypt) =================
+ * Off the hot path; needed so tests can assert decrypt-correctness like the reference's tests.
+ * Own deterministic RNG (the reference uses thread_rng, unseeded).  Noise is a two-sided rounded
+ * Gaussian unless literal_noise != 0, in which case negative samples saturate to 0 exactly as
+ * `frac as u32` does in utils.rs:36-41. */
+typedef struct {
+    uint64_t state;
+    int literal_noise;
+    int have_spare;
+    double spare;
+} orc_rng;
+
+void orc_rng_seed(orc_rng *r, uint64_t seed);
+uint64_t orc_rng_next_u64(orc_rng *r);     /* SplitMix64 */
+uint32_t orc_rng_next_u32(orc_rng *r);
+void orc_fill_uniform_u32(orc_rng *r, uint32_t *out, size_t len);
+uint32_t orc_f64_to_torus(double v, int literal);                              /* utils.rs:36-41 */
+uint32_t orc_sample_gaussian(orc_rng *r, double std_dev);                      /* utils.rs:43-54 */
+void orc_sample_binary(orc_rng *r, uint32_t *out, size_t len);                 /* utils.rs:68-93 */
+
+void orc_lwe_secret_key_random(const orc_params *p, orc_rng *r, uint32_t *sk /* n */);      /* lwe.rs:53-60 */
+void orc_glwe_secret_key_random(const orc_params *p, orc_rng *r, uint32_t *sk /* k x N */); /* glwe.rs:176-182 */
+int orc_lwe_encode(const orc_params *p, uint32_t m, uint32_t *pt);             /* lwe.rs:81-92 */
+uint32_t orc_lwe_decode(const orc_params *p, uint32_t pt);                     /* lwe.rs:100-107 */
+void orc_encrypt_lwe_plaintext(size_t n, double std_dev, const uint32_t *sk, uint32_t pt,
+                               orc_rng *r, uint32_t *ct /* n+1 */);            /* lwe.rs:138-160 */
+uint32_t orc_decrypt_lwe(size_t n, const uint32_t *sk, const uint32_t *ct);    /* lwe.rs:162-173 */
+void orc_encrypt_glwe_zero(const orc_params *p, const uint32_t *sk, orc_rng *r,
+                           uint32_t *ct /* (k+1) x N */);                      /* glwe.rs:190-209 */
+void orc_encrypt_glwe_plaintext(const orc_params *p, const uint32_t *pt, const uint32_t *sk,
+                                orc_rng *r, uint32_t *ct);                     /* glwe.rs:211-230 */
+void orc_decrypt_glwe_ciphertext(const orc_params *p, const uint32_t *sk, const uint32_t *ct,
+                                 uint32_t *pt /* N */);                        /* glwe.rs:245-265 */
+void orc_encrypt_ggsw_plaintext(const orc_params *p, uint32_t message, const uint32_t *glwe_sk,
+                                orc_rng *r, uint32_t *ggsw /* R x (k+1) x N */);  /* ggsw.rs:76-130 */
+void orc_generate_ksk(const uint32_t *from_sk, size_t from_n, const uint32_t *to_sk, size_t to_n,
+                      double to_std_dev, const orc_decomposer *d, orc_rng *r,
+                      uint32_t *ksk /* from_n*levels x (to_n+1) */);           /* key_switching.rs:20-60 */
+/* bootstrapping.rs:23-56: bsk [n][R][k+1][N], ksk [kN*l_ks][n+1] */
+void orc_bootstrapping_key_gen(const orc_params *p, const uint32_t *lwe_sk,
+                               const uint32_t *glwe_sk, orc_rng *r, uint32_t *bsk, uint32_t *ksk);
+
+/* sizes (in u32 words) */
+size_t orc_ggsw_words(const orc_params *p);
+size_t orc_bsk_words(const orc_params *p);
+size_t orc_ksk_words(const orc_params *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
