@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py -- programmable bootstraps per second on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path (bootstrap(): blind rotation + sample extract + key switch,
+reference bootstrapping.rs:58-120) over one batch of synthetic LWE ciphertexts that is already
+resident in HBM.  Default workload = BASELINE.json configs[1]: batch 4096, N=1024, k=1, n=630,
+l=3, log2B=7 (KS log2B=4, l=5; log_p=2, padding 1 as fixed in SURVEY 8d), identity LUT.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: independent LWE bootstraps shard across ranks with no data-path collective (keys are
+replicated per GPU); weak scaling: every rank processes `--batch` ciphertexts per step.  The only
+collectives are the timing barrier / max-reduction (RCCL).
+
+Rank 0 prints ONE JSON line.  Besides the contract keys it carries
+  roofline     : the blind-rotation kernel (the dominant one) against the HBM roofline, priced in
+                 ALGORITHMIC bytes = external products x 4*N*(k+1)*((k+1)*l+2) bytes,
+                 duration measured with HIP events on the kernel's own stream during the timed
+                 region;
+  cpu_baseline : the literal CPU restatement of the reference (oracle, kind "port": the Rust
+                 reference cannot be built in this image) timed single-threaded on a bounded
+                 sample of the same workload, on this box's host cores (N=1, rank 0 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+
+WORKLOADS = {
+    # name: (k, logN, n, (pbs logB, l), (ks logB, l), log_p, default batch)
+    "cfg2": (1, 10, 630, (7, 3), (4, 5), 2, 4096),
+    "cfg3": (2, 9, 722, (4, 6), (4, 5), 2, 4096),
+    "cfg1": (1, 9, 500, (8, 2), (4, 5), 2, 4096),
+    "cfg5": (2, 11, 630, (8, 4), (4, 5), 4, 512),
+}
+
+
+def cpu_baseline(workload: str, budget_s: float):
+    """Time the oracle's literal path (Toeplitz matrix + mat-vec, as the reference does) on a bounded
+    sample: whole bootstraps of the same parameter set, single thread (the reference is
+    single-threaded)."""
+    from oracle import oracle as orc
+    orc.build()
+    k, logn, n, pbs, ks, log_p, _ = WORKLOADS[workload]
+    p = orc.Params(k, logn, n, orc.Decomposer(*pbs), orc.Decomposer(*ks), log_p=log_p)
+    lwe, bsk, ksk, tv = orc.synthetic_inputs(p, 8, cfg_index=2)
+    orc.set_poly_mul_mode(0)
+    done, t0 = 0, time.perf_counter()
+    while done < lwe.shape[0]:
+        orc.bootstrap(p, lwe[done], bsk, ksk, tv)
+        done += 1
+        if time.perf_counter() - t0 >= budget_s:
+            break
+    dt = time.perf_counter() - t0
+    orc.set_poly_mul_mode(1)
+    return {
+        "value": done / dt, "unit": "PBS/s", "cores": 1, "kind": "port",
+        "sample": f"{done} full bootstraps of {workload} (literal Toeplitz path, gcc -O2, 1 thread) in {dt:.1f} s",
+        "host_cores_available": os.cpu_count(),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=0, help="ciphertexts per GPU per step (default: workload's)")
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    pkg = entry.load_package()
+    k, logn, n, pbs, ks, log_p, default_batch = WORKLOADS[args.workload]
+    batch = args.batch or default_batch
+    params = pkg.TfheParams(k, logn, n, pkg.DecomposerParams(*pbs), pkg.DecomposerParams(*ks), log_p=log_p)
+
+    # synthetic, uniformly random u32 words (the arithmetic is total); HBM resident before timing
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0x74666865 + rank)
+
+    def rand_words(*shape):
+        return torch.randint(-(1 << 31), (1 << 31) - 1, shape, dtype=torch.int32, device=dev, generator=gen)
+
+    lwe = rand_words(batch, n + 1)
+    bsk = rand_words(*params.bsk_shape())
+    ksk = rand_words(*params.ksk_shape())
+    tv = torch.from_numpy(pkg.construct_identity_test_vector(params).astype(np.int32)).to(dev)
+    out = torch.empty_like(lwe)
+
+    ctx = pkg.Context(params, device=local_rank)
+    ctx.use_torch_stream()
+    ctx.load_bootstrapping_key(bsk, ksk)
+    del bsk
+    ctx.reserve(batch)
+    ctx.set_timing(True)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ctx.bootstrap(lwe, tv, out=out)
+    barrier()
+    br_ms, ks_ms = [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctx.bootstrap(lwe, tv, out=out)
+        b, s = ctx.last_kernel_ms()  # waits for this step's events on the kernel's own stream
+        br_ms.append(b)
+        ks_ms.append(s)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    total = batch * world * args.steps
+    value = total / dt
+    br_avg = float(np.mean(br_ms))
+    ks_avg = float(np.mean(ks_ms))
+    ext_products = batch * n  # per launch
+    algo_bytes = ext_products * params.external_product_bytes()
+    achieved = algo_bytes / (br_avg * 1e-3) / 1e9
+    result = {
+        "metric": "programmable_bootstraps_per_sec",
+        "value": value,
+        "unit": "PBS/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u64 (exact Goldilocks NTT of wrapping-u32 data)",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{args.workload}: batch {batch}/GPU, N={1 << logn}, k={k}, n={n}, l={pbs[1]}, log2B={pbs[0]}, "
+                        f"KS l={ks[1]} log2B={ks[0]}, log_p={log_p}, identity LUT",
+            "global_batch": batch * world,
+            "parallelism": f"dp{world} (independent LWE shards, keys replicated)",
+        },
+        "roofline": {
+            "kernel": f"blind_rotate_kernel<{logn},{k}>",
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "kernel_ms": br_avg,
+            "algorithmic_bytes_per_launch": algo_bytes,
+            "external_products_per_s": ext_products / (br_avg * 1e-3),
+            "key_switch_kernel_ms": ks_avg,
+            "note": "integer-VALU bound by design (SURVEY 8d); HBM fraction reported as the metric asks",
+        },
+    }
+    ctx.close()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_baseline_seconds)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

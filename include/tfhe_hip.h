@@ -1,0 +1,181 @@
+/*
+ * tfhe_hip.h -- C ABI of the MI355X-native TFHE programmable-bootstrapping engine.
+ *
+ * Drop-in boundary for the bootstrapping path of Janmajayamall/tfhe-research (Rust crate `tfhe`
+ * v0.1.0).  The reference has no FFI of its own (all modules are private, no extern "C"); each
+ * entry point below replaces one crate-internal function and takes that function's data in the
+ * reference's own memory layout: contiguous row-major u32 ndarrays viewed as `*const u32 + len`
+ * (the reference relies on `as_slice().unwrap()`, e.g. bootstrapping.rs:68, key_switching.rs:73).
+ * Reference citations are file:line under /root/reference/src.
+ *
+ * Conventions
+ *   - every word is uint32_t, arithmetic wraps mod 2^32 (reference release-mode semantics);
+ *   - every call returns an int status (0 = ok); nothing throws or unwinds across this boundary
+ *     (the reference signals failure by panicking: assert!/unwrap);
+ *   - plain entry points take HOST pointers, block until the result is in host memory, and may
+ *     be called from any thread (one context = one stream; do not share a context between
+ *     threads without external locking);
+ *   - `_device` entry points take DEVICE pointers, enqueue on the context's HIP stream and
+ *     return without synchronising; they are graph-capture safe (no allocation, no sync);
+ *   - the two unused secret-key arguments of the reference's bootstrap()/and()/or()
+ *     (bootstrapping.rs:61-62, boolean.rs:16,39) carry no information and do not cross the ABI.
+ */
+#ifndef TFHE_HIP_H
+#define TFHE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TFHE_OK 0
+#define TFHE_ERR_INVALID_PARAMS 1   /* parameter set the reference itself could not run */
+#define TFHE_ERR_UNSUPPORTED 2      /* valid, but no kernel is instantiated for this shape */
+#define TFHE_ERR_NO_KEY 3           /* bootstrapping key not loaded */
+#define TFHE_ERR_HIP 4              /* HIP runtime error (see tfhe_last_error) */
+#define TFHE_ERR_INVALID_ARGUMENT 5 /* null pointer / bad count / value the reference assert!s on */
+#define TFHE_ERR_NO_DEVICE 6        /* no usable GPU: this library has no CPU fallback */
+#define TFHE_ERR_EXACTNESS 7        /* parameter set exceeds the exact-NTT bound */
+
+/* decomposer.rs:2-6 DecomposerParams */
+typedef struct tfhe_decomposer_params {
+    uint32_t log_base;
+    uint32_t levels;
+    uint32_t log_q;
+} tfhe_decomposer_params;
+
+/* lib.rs:23-34 TfheParams (noise parameters omitted: they only matter for key generation).
+ * glwe_poly_degree is log2(N), exactly as in the reference (lib.rs:40,60). */
+typedef struct tfhe_params {
+    uint32_t glwe_dimension;   /* k */
+    uint32_t glwe_poly_degree; /* log2 N, supported: 9, 10, 11 */
+    uint32_t lwe_dimension;    /* n */
+    uint32_t padding_bits;
+    uint32_t log_p;
+    uint32_t log_q;            /* must be 32 */
+    tfhe_decomposer_params ks_decomposer;
+    tfhe_decomposer_params pbs_decomposer;
+} tfhe_params;
+
+typedef struct tfhe_context tfhe_context;
+
+/* Which decomposer of the parameter set an entry point should use. */
+#define TFHE_DECOMPOSER_PBS 0
+#define TFHE_DECOMPOSER_KS 1
+
+/* ---- parameters / context --------------------------------------------------------------- */
+
+/* lib.rs:101-123 (cfg_test = 0) or lib.rs:77-99 (cfg_test = 1: n = 4) */
+void tfhe_params_default(tfhe_params *params, int cfg_test);
+/* 0 if the reference could run this parameter set (no underflow / endless loop / shift >= 32) */
+int tfhe_params_validate(const tfhe_params *params);
+
+/* Creates a context bound to HIP device `device`.  Fails with TFHE_ERR_NO_DEVICE when no GPU is
+ * present: there is deliberately no CPU path behind this ABI. */
+int tfhe_context_create(const tfhe_params *params, int device, tfhe_context **out);
+void tfhe_context_destroy(tfhe_context *ctx);
+/* Use an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream. */
+int tfhe_context_set_stream(tfhe_context *ctx, void *hip_stream);
+int tfhe_context_synchronize(tfhe_context *ctx);
+/* Pre-sizes the per-batch workspace so that later _device calls up to `max_batch` never allocate. */
+int tfhe_context_reserve(tfhe_context *ctx, size_t max_batch);
+const char *tfhe_last_error(const tfhe_context *ctx);
+const char *tfhe_status_string(int status);
+
+/* ---- key upload: BootstrappingKey (bootstrapping.rs:18-21) ------------------------------- */
+/* bsk: the n GGSW ciphertexts of lwe_sk_ggsw_enc back to back, [n][(k+1)*l][k+1][N]
+ *      (ggsw.rs:37-41: row = poly_index*l + level, each row one GLWE, body last);
+ * ksk: KeySwitchingKey.data, [k*N*l_ks][n+1] (key_switching.rs:13-15).
+ * The device keeps the BSK in the NTT domain (u64, pre-scaled by 1/N) and the KSK as is. */
+int tfhe_load_bootstrapping_key(tfhe_context *ctx, const uint32_t *bsk, const uint32_t *ksk);
+int tfhe_load_bootstrapping_key_device(tfhe_context *ctx, const uint32_t *bsk, const uint32_t *ksk);
+
+/* ---- bootstrap(): bootstrapping.rs:58-120 ------------------------------------------------- */
+/* lwe_in  [batch][n+1]   LweCiphertext.data (a_0..a_{n-1}, b)              (lwe.rs:110-115)
+ * test_vector_poly [tv_count][N], tv_count = 1 (shared) or batch; un-encoded values < 2^log_p,
+ *         as produced by construct_test_from_lut (encoded on the device: glwe.rs:141-151)
+ * lwe_out [batch][n+1] */
+int tfhe_bootstrap_batch(tfhe_context *ctx, const uint32_t *lwe_in, size_t batch,
+                         const uint32_t *test_vector_poly, size_t tv_count, uint32_t *lwe_out);
+int tfhe_bootstrap_batch_device(tfhe_context *ctx, const uint32_t *lwe_in, size_t batch,
+                                const uint32_t *test_vector_poly, size_t tv_count,
+                                uint32_t *lwe_out);
+
+/* Blind rotation only (bootstrapping.rs:67-105): glwe_out [batch][k+1][N] */
+int tfhe_blind_rotate_batch(tfhe_context *ctx, const uint32_t *lwe_in, size_t batch,
+                            const uint32_t *test_vector_poly, size_t tv_count, uint32_t *glwe_out);
+int tfhe_blind_rotate_batch_device(tfhe_context *ctx, const uint32_t *lwe_in, size_t batch,
+                                   const uint32_t *test_vector_poly, size_t tv_count,
+                                   uint32_t *glwe_out);
+
+/* sample_extract(): bootstrapping.rs:122-156.  glwe [batch][k+1][N] -> lwe_out [batch][k*N+1] */
+int tfhe_sample_extract_batch(tfhe_context *ctx, const uint32_t *glwe, size_t batch,
+                              size_t sample_index, uint32_t *lwe_out);
+
+/* key_switch_lwe(): key_switching.rs:63-103 with the loaded KSK (from dimension k*N to n).
+ * lwe_in [batch][k*N+1] -> lwe_out [batch][n+1] */
+int tfhe_key_switch_batch(tfhe_context *ctx, const uint32_t *lwe_in, size_t batch,
+                          uint32_t *lwe_out);
+int tfhe_key_switch_batch_device(tfhe_context *ctx, const uint32_t *lwe_in, size_t batch,
+                                 uint32_t *lwe_out);
+
+/* ---- ggsw.rs ------------------------------------------------------------------------------ */
+/* external_product(): ggsw.rs:132-161.  ggsw [ggsw_count][(k+1)*l][k+1][N] with ggsw_count = 1
+ * (one GGSW for the whole batch, the blind-rotation shape) or batch; glwe [batch][k+1][N]. */
+int tfhe_external_product_batch(tfhe_context *ctx, const uint32_t *ggsw, size_t ggsw_count,
+                                const uint32_t *glwe_in, size_t batch, uint32_t *glwe_out);
+/* Device-pointer form used by the benchmark: `ggsw_prepared` comes from tfhe_prepare_ggsw_device. */
+int tfhe_prepare_ggsw_device(tfhe_context *ctx, const uint32_t *ggsw, size_t ggsw_count,
+                             uint64_t *ggsw_prepared);
+int tfhe_external_product_prepared_device(tfhe_context *ctx, const uint64_t *ggsw_prepared,
+                                          size_t ggsw_count, const uint32_t *glwe_in, size_t batch,
+                                          uint32_t *glwe_out);
+/* cmux(): ggsw.rs:164-178.  Like the reference, ct1 is CLOBBERED with ct1 - ct0. */
+int tfhe_cmux_batch(tfhe_context *ctx, const uint32_t *ggsw, size_t ggsw_count,
+                    const uint32_t *ct0, uint32_t *ct1, size_t batch, uint32_t *glwe_out);
+
+/* ---- decomposer.rs / glwe.rs / utils.rs --------------------------------------------------- */
+/* SignedDecomposer::decompose: decomposer.rs:42-80.  digits_out [count][levels], MSB first. */
+int tfhe_decompose(tfhe_context *ctx, int which_decomposer, const uint32_t *values, size_t count,
+                   uint32_t *digits_out);
+/* decompose_glwe_ciphertext: glwe.rs:90-108.  glwe [batch][k+1][N] -> [batch][(k+1)*l][N] */
+int tfhe_decompose_glwe_batch(tfhe_context *ctx, const uint32_t *glwe, size_t batch,
+                              uint32_t *digits_out);
+/* switch_modulus: utils.rs:23-33 */
+int tfhe_switch_modulus(tfhe_context *ctx, const uint32_t *values, size_t count, uint32_t log_from,
+                        uint32_t log_to, uint32_t *out);
+/* &GlweCiphertext * &Monomial: glwe.rs:20-34, one monomial index per ciphertext */
+int tfhe_glwe_mul_monomial_batch(tfhe_context *ctx, const uint32_t *glwe_in, size_t batch,
+                                 const int64_t *monomial_index, uint32_t *glwe_out);
+
+/* ---- test_vector.rs / boolean.rs ---------------------------------------------------------- */
+/* construct_test_from_lut: test_vector.rs:38-67 (host-side, no GPU).  out [N] */
+int tfhe_construct_test_from_lut(const tfhe_params *params, const uint32_t *lut, size_t lut_len,
+                                 uint32_t *out);
+/* construct_test_vector_boolean: test_vector.rs:5-20 with the closure given as its truth table
+ * truth[(lhs << 1) | rhs] */
+int tfhe_construct_test_vector_boolean(const tfhe_params *params, const uint32_t truth[4],
+                                       uint32_t *out);
+/* and()/or(): boolean.rs:9-53 generalised over the closure: out = bootstrap(2*ct1 + ct0) with the
+ * closure's test vector.  AND = {0,0,0,1}, OR = {0,1,1,1}, NAND = {1,1,1,0}, XOR = {0,1,1,0}. */
+int tfhe_gate_batch(tfhe_context *ctx, const uint32_t truth[4], const uint32_t *ct0,
+                    const uint32_t *ct1, size_t batch, uint32_t *lwe_out);
+int tfhe_gate_batch_device(tfhe_context *ctx, const uint32_t truth[4], const uint32_t *ct0,
+                           const uint32_t *ct1, size_t batch, uint32_t *lwe_out);
+
+/* ---- introspection for benchmarks --------------------------------------------------------- */
+/* Time of the blind-rotation kernel of the most recent bootstrap/blind_rotate call, measured with
+ * HIP events on the context's stream (milliseconds); negative if none was recorded.  Enable with
+ * tfhe_context_set_timing(ctx, 1): the _device calls then record events (still no sync). */
+int tfhe_context_set_timing(tfhe_context *ctx, int enable);
+int tfhe_last_kernel_ms(tfhe_context *ctx, float *blind_rotate_ms, float *key_switch_ms);
+
+/* Library / build identification */
+const char *tfhe_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

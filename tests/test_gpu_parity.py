@@ -1,0 +1,192 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against
+the CPU oracle on the same seeded inputs -- bit-exact, all arithmetic is wrapping u32."""
+import numpy as np
+import pytest
+
+from gpu_common import pkg, rand_u32, to_pkg_params
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [
+    # name, k, logN, n, pbs(logB, l), ks(logB, l), log_p
+    ("ref_test", 2, 9, 4, (4, 6), (4, 5), 2),      # reference cfg(test) parameters (lib.rs:77-99)
+    ("cfg1_small", 1, 9, 6, (8, 2), (4, 5), 2),
+    ("cfg2_small", 1, 10, 5, (7, 3), (4, 5), 2),   # misaligned base: literal decomposer quirk
+    ("cfg5_small", 2, 11, 2, (8, 4), (4, 5), 4),
+    ("k2_n1024", 2, 10, 3, (4, 7), (8, 3), 3),
+    ("k1_n2048", 1, 11, 2, (16, 2), (2, 9), 2),
+]
+
+
+def make(oracle, k, logn, n, pbs, ks, log_p):
+    return oracle.Params(k, logn, n, oracle.Decomposer(*pbs), oracle.Decomposer(*ks), log_p=log_p)
+
+
+@pytest.fixture(scope="module")
+def contexts(oracle):
+    made = {}
+
+    def get(name):
+        if name not in made:
+            spec = next(s for s in SHAPES if s[0] == name)
+            p = make(oracle, *spec[1:])
+            batch = 9  # not a multiple of the waves per workgroup: exercises the ragged tail
+            lut = np.random.default_rng(len(name)).integers(0, 1 << p.log_p, size=1 << p.log_p)
+            lwe, bsk, ksk, tv = oracle.synthetic_inputs(p, batch, cfg_index=70 + len(made), lut=lut)
+            lwe = lwe.copy()
+            lwe[0, 0] = 0             # a~ = 0 -> skipped CMUX
+            lwe[1, p.n] = 0xFFFFFFFF  # b~ rounds to 2N and wraps to 0
+            lwe[2, :] = 0x80000000
+            ctx = pkg().Context(to_pkg_params(p))
+            ctx.load_bootstrapping_key(bsk, ksk)
+            made[name] = (p, ctx, lwe, bsk, ksk, tv)
+        return made[name]
+
+    yield get
+    for _, ctx, *_ in made.values():
+        ctx.close()
+
+
+@pytest.mark.parametrize("name", [s[0] for s in SHAPES])
+def test_bootstrap_matches_oracle(oracle, contexts, name):
+    p, ctx, lwe, bsk, ksk, tv = contexts(name)
+    got = ctx.bootstrap(lwe, tv)
+    glwe = ctx.blind_rotate(lwe, tv)
+    for b in range(lwe.shape[0]):
+        want, tr = oracle.bootstrap(p, lwe[b], bsk, ksk, tv, trace=True)
+        assert np.array_equal(glwe[b], tr["acc_final"]), f"{name}: blind rotation, sample {b}"
+        assert np.array_equal(got[b], want), f"{name}: bootstrap, sample {b}"
+    # per-sample test vectors
+    tvs = np.stack([np.roll(tv, b) for b in range(lwe.shape[0])])
+    got2 = ctx.bootstrap(lwe, tvs)
+    for b in (0, 3, 8):
+        assert np.array_equal(got2[b], oracle.bootstrap(p, lwe[b], bsk, ksk, tvs[b]))
+    # single ciphertext (the reference's call shape)
+    assert np.array_equal(ctx.bootstrap(lwe[4], tv), got[4])
+
+
+@pytest.mark.parametrize("name", [s[0] for s in SHAPES])
+def test_external_product_and_cmux(oracle, contexts, name):
+    p, ctx, *_ = contexts(name)
+    rng = np.random.default_rng(3)
+    batch = 5
+    ggsw = rand_u32(rng, (batch, p.R, p.k + 1, p.N))
+    ct0 = rand_u32(rng, (batch, p.k + 1, p.N))
+    ct1 = rand_u32(rng, (batch, p.k + 1, p.N))
+    ct0[:, :, :4] = [0xFFFFFFFF, 0x7FFFFFFF, 0x80000000, 0xF8F8F8F8]
+    # one GGSW per sample
+    got = ctx.external_product(ggsw, ct0)
+    for b in range(batch):
+        assert np.array_equal(got[b], oracle.external_product(p, ggsw[b], ct0[b])), (name, b)
+    # one GGSW shared by the batch (the blind-rotation shape)
+    got = ctx.external_product(ggsw[0], ct0)
+    for b in range(batch):
+        assert np.array_equal(got[b], oracle.external_product(p, ggsw[0], ct0[b])), (name, b)
+    res, clob = ctx.cmux(ggsw, ct0, ct1)
+    for b in range(batch):
+        want, want_clob = oracle.cmux(p, ggsw[b], ct0[b], ct1[b])
+        assert np.array_equal(res[b], want) and np.array_equal(clob[b], want_clob), (name, b)
+
+
+@pytest.mark.parametrize("name", [s[0] for s in SHAPES])
+def test_key_switch_and_sample_extract(oracle, contexts, name):
+    p, ctx, lwe, bsk, ksk, tv = contexts(name)
+    rng = np.random.default_rng(4)
+    batch = 37
+    big = rand_u32(rng, (batch, p.big_n + 1))
+    got = ctx.key_switch(big)
+    for b in (0, 1, 17, 36):
+        assert np.array_equal(got[b], oracle.key_switch_lwe(big[b], p.big_n, p.n, p.ks, ksk)), (name, b)
+    glwe = rand_u32(rng, (3, p.k + 1, p.N))
+    for idx in (0, 1, p.N // 2, p.N - 1):
+        got = ctx.sample_extract(glwe, idx)
+        for b in range(3):
+            assert np.array_equal(got[b], oracle.sample_extract(p, glwe[b], idx)), (name, idx, b)
+
+
+def test_small_ops(oracle, contexts):
+    p, ctx, *_ = contexts("cfg2_small")
+    rng = np.random.default_rng(5)
+    v = rand_u32(rng, 10000)
+    v[:6] = [0, 1, 0xFFFFFFFF, 0x80000000, 0xF8F8F8F8, 0x00000F80]
+    m = pkg()
+    assert np.array_equal(ctx.decompose(v, m.DECOMPOSER_PBS), oracle.decompose(p.pbs, v))
+    assert np.array_equal(ctx.decompose(v, m.DECOMPOSER_KS), oracle.decompose(p.ks, v))
+    for log_to in (1, 10, 11, 12, 31):
+        assert np.array_equal(ctx.switch_modulus(v, 32, log_to), oracle.switch_modulus(v, 32, log_to))
+    glwe = rand_u32(rng, (4, p.k + 1, p.N))
+    assert np.array_equal(ctx.decompose_glwe(glwe)[2], oracle.decompose_glwe_ciphertext(glwe[2], p.pbs))
+    idx = np.array([-1, 0, p.N + 3, -(5 * p.N) - 7], dtype=np.int64)
+    got = ctx.glwe_mul_monomial(glwe, idx)
+    for b in range(4):
+        assert np.array_equal(got[b], oracle.glwe_mul_monomial(glwe[b], int(idx[b])))
+    for lut in ([0, 1, 2, 3], [3, 1, 0, 2]):
+        assert np.array_equal(m.construct_test_from_lut(to_pkg_params(p), lut), oracle.construct_test_from_lut(p, lut))
+
+
+def test_gates_bit_exact_and_decrypt(oracle):
+    """boolean.rs:67-101: truth table through real keys, plus NAND/OR/XOR via the closure hook;
+    outputs bit-exact vs the oracle AND decrypting to the right bit."""
+    p = oracle.REF_TEST
+    rng = oracle.Rng(2024)
+    lwe_sk, glwe_sk, bsk, ksk = oracle.keygen(p, rng)
+    m = pkg()
+    with m.Context(to_pkg_params(p)) as ctx:
+        ctx.load_bootstrapping_key(bsk, ksk)
+        gates = {"and": (m.GATE_AND, lambda l, r: l & r), "or": (m.GATE_OR, lambda l, r: l | r),
+                 "nand": (m.GATE_NAND, lambda l, r: 1 - (l & r)), "xor": (m.GATE_XOR, lambda l, r: l ^ r)}
+        ct1 = np.stack([oracle.encrypt_lwe(p, lwe_sk, (i >> 1) & 1, rng) for i in range(4)])
+        ct0 = np.stack([oracle.encrypt_lwe(p, lwe_sk, i & 1, rng) for i in range(4)])
+        for name, (truth, f) in gates.items():
+            out = ctx.gate(truth, ct0, ct1)
+            for i in range(4):
+                assert np.array_equal(out[i], oracle.boolean_gate(p, f, ct0[i], ct1[i], bsk, ksk)), name
+                assert oracle.decrypt_lwe_message(p, lwe_sk, out[i]) == f((i >> 1) & 1, i & 1), name
+        # identity-LUT PBS refreshes every message (bootstrapping.rs:194-230)
+        tv = m.construct_identity_test_vector(to_pkg_params(p))
+        cts = np.stack([oracle.encrypt_lwe(p, lwe_sk, msg, rng) for msg in range(4)])
+        out = ctx.bootstrap(cts, tv)
+        for msg in range(4):
+            assert oracle.decrypt_lwe_message(p, lwe_sk, out[msg]) == msg
+
+
+def test_error_behaviour(oracle):
+    """The reference panics (assert!/unwrap); across the C ABI those become status codes."""
+    m = pkg()
+    p = oracle.REF_TEST
+    with pytest.raises(m.TfheError) as e:  # levels > floor(32/log_base): endless loop in the reference
+        m.Context(m.TfheParams(1, 10, 8, m.DecomposerParams(7, 5)))
+    assert e.value.status == 1
+    with pytest.raises(m.TfheError) as e:  # N = 256 has no kernel
+        m.Context(m.TfheParams(1, 8, 8, m.DecomposerParams(4, 6)))
+    assert e.value.status == 2
+    with m.Context(to_pkg_params(p)) as ctx:
+        lwe = np.zeros((2, p.n + 1), dtype=np.uint32)
+        tv = np.zeros(p.N, dtype=np.uint32)
+        with pytest.raises(m.TfheError) as e:  # no key loaded
+            ctx.bootstrap(lwe, tv)
+        assert e.value.status == 3
+        _, bsk, ksk, _ = oracle.synthetic_inputs(p, 1, cfg_index=1)
+        ctx.load_bootstrapping_key(bsk, ksk)
+        tv[5] = 4  # glwe.rs:144 assert!(m < 2^log_p)
+        with pytest.raises(m.TfheError) as e:
+            ctx.bootstrap(lwe, tv)
+        assert e.value.status == 5
+        with pytest.raises(m.TfheError) as e:  # bootstrapping.rs:127 assert!(sample_index < N)
+            ctx.sample_extract(np.zeros((1, p.k + 1, p.N), dtype=np.uint32), p.N)
+        assert e.value.status == 5
+
+
+def test_full_size_cfg2_sample_parity(oracle):
+    """BASELINE cfg2 at full size (N=1024, k=1, n=630, l=3, logB=7): a batch of 64 on the GPU, three
+    samples checked against the oracle end to end (each oracle PBS is ~8 G u32 MACs)."""
+    p = oracle.CFG2
+    lwe, bsk, ksk, tv = oracle.synthetic_inputs(p, 64, cfg_index=2)
+    m = pkg()
+    with m.Context(to_pkg_params(p)) as ctx:
+        ctx.load_bootstrapping_key(bsk, ksk)
+        out = ctx.bootstrap(lwe, tv)
+        # determinism: same inputs, same bits
+        assert np.array_equal(out, ctx.bootstrap(lwe, tv))
+    for b in (0, 31, 63):
+        assert np.array_equal(out[b], oracle.bootstrap(p, lwe[b], bsk, ksk, tv)), b

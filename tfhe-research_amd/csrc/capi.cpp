@@ -1,0 +1,733 @@
+// capi.cpp -- implementation of the C ABI declared in include/tfhe_hip.h.
+//
+// Host-side only logic: parameter validation (mirrors what makes the reference panic), device
+// memory management, key preparation and kernel sequencing.  No CPU implementation of the hot
+// path lives here: without a GPU every compute entry point fails with TFHE_ERR_NO_DEVICE.
+#include "tfhe_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "launch.h"
+
+using namespace tfhe;
+
+struct tfhe_context {
+  tfhe_params params;
+  PbsParams pbs;
+  KsParams ks;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  u32 N = 0, R = 0, big_n = 0;
+
+  u64* d_tw = nullptr;        // psi_rev[N]
+  u64* d_bsk = nullptr;       // prepared BSK [n][R][k+1][N] u64 (spectrum_slot order, x 1/N)
+  u32* d_ksk = nullptr;       // [big_n*l_ks][n+1]
+  bool have_key = false;
+
+  // workspace (grown on demand by host-pointer calls or tfhe_context_reserve)
+  size_t ws_batch = 0;
+  u32* d_lwe_in = nullptr;    // [batch][n+1]
+  u32* d_lwe_in2 = nullptr;   // [batch][n+1] second gate operand
+  u32* d_lwe_big = nullptr;   // [batch][big_n+1]
+  u32* d_lwe_out = nullptr;   // [batch][n+1]
+  u32* d_glwe_a = nullptr;    // [batch][k+1][N]
+  u32* d_glwe_b = nullptr;
+  u32* d_glwe_c = nullptr;
+  u32* d_tv = nullptr;        // [batch][N] (or [1][N])
+  u32* d_tv_gate = nullptr;   // [N] test vector of gate calls
+  // generic scratch for the small entry points
+  void* d_misc = nullptr;
+  size_t misc_bytes = 0;
+  u64* d_ggsw_tmp = nullptr;  // prepared GGSWs of external_product / cmux host calls
+  size_t ggsw_tmp_words = 0;
+  u32* d_ggsw_raw = nullptr;
+  size_t ggsw_raw_words = 0;
+
+  bool timing = false;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // br start/stop, ks start/stop
+  bool ev_valid_br = false, ev_valid_ks = false;
+
+  std::string last_error;
+};
+
+namespace {
+
+int fail(tfhe_context* ctx, int status, const std::string& msg) {
+  if (ctx) ctx->last_error = msg;
+  return status;
+}
+
+int hip_fail(tfhe_context* ctx, hipError_t e, const char* what) {
+  return fail(ctx, TFHE_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIP_TRY(ctx, expr)                                        \
+  do {                                                            \
+    hipError_t _e = (expr);                                       \
+    if (_e != hipSuccess) return hip_fail((ctx), _e, #expr);      \
+  } while (0)
+
+int decomposer_validate(const tfhe_decomposer_params& d) {
+  if (d.log_q != 32) return 1;                        // the reference is hard-typed to u32
+  if (d.log_base == 0 || d.log_base >= 32) return 2;  // 1 << (log_base - 1), 1 << log_base
+  if (d.levels == 0) return 3;
+  if (d.log_base * d.levels > d.log_q) return 4;      // usize underflow, decomposer.rs:28
+  if (d.levels > d.log_q / d.log_base) return 5;      // truncation loop never ends, :74-77
+  return 0;
+}
+
+template <typename T>
+int ensure(tfhe_context* ctx, T** ptr, size_t* have, size_t want_elems) {
+  if (*have >= want_elems && *ptr) return TFHE_OK;
+  if (*ptr) HIP_TRY(ctx, hipFree(*ptr));
+  *ptr = nullptr;
+  *have = 0;
+  HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(ptr), want_elems * sizeof(T)));
+  *have = want_elems;
+  return TFHE_OK;
+}
+
+int reserve(tfhe_context* ctx, size_t batch) {
+  if (batch <= ctx->ws_batch) return TFHE_OK;
+  const size_t n1 = (size_t)ctx->params.lwe_dimension + 1;
+  const size_t glwe = (size_t)(ctx->params.glwe_dimension + 1) * ctx->N;
+  u32** ptrs[] = {&ctx->d_lwe_in, &ctx->d_lwe_in2, &ctx->d_lwe_big, &ctx->d_lwe_out,
+                  &ctx->d_glwe_a, &ctx->d_glwe_b,   &ctx->d_glwe_c,  &ctx->d_tv};
+  const size_t sizes[] = {batch * n1, batch * n1, batch * ((size_t)ctx->big_n + 1), batch * n1,
+                          batch * glwe, batch * glwe, batch * glwe, batch * ctx->N};
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < 8; ++i) {
+    if (*ptrs[i]) HIP_TRY(ctx, hipFree(*ptrs[i]));
+    *ptrs[i] = nullptr;
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(ptrs[i]), sizes[i] * sizeof(u32)));
+  }
+  ctx->ws_batch = batch;
+  return TFHE_OK;
+}
+
+int ensure_misc(tfhe_context* ctx, size_t bytes) {
+  if (bytes <= ctx->misc_bytes) return TFHE_OK;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->d_misc) HIP_TRY(ctx, hipFree(ctx->d_misc));
+  ctx->d_misc = nullptr;
+  ctx->misc_bytes = 0;
+  HIP_TRY(ctx, hipMalloc(&ctx->d_misc, bytes));
+  ctx->misc_bytes = bytes;
+  return TFHE_OK;
+}
+
+int check_ctx(tfhe_context* ctx) {
+  if (!ctx) return TFHE_ERR_INVALID_ARGUMENT;
+  hipError_t e = hipSetDevice(ctx->device);
+  if (e != hipSuccess) return hip_fail(ctx, e, "hipSetDevice");
+  return TFHE_OK;
+}
+
+// construct_test_from_lut: test_vector.rs:38-67
+int test_from_lut(const tfhe_params* p, const u32* lut, size_t lut_len, u32* out) {
+  const u32 plaintext_modulus = 1u << p->log_p;
+  if (lut_len != plaintext_modulus) return TFHE_ERR_INVALID_ARGUMENT;  // assert! :41
+  const size_t n = (size_t)1 << p->glwe_poly_degree;
+  const size_t repetition = n / ((size_t)1 << p->log_p);
+  std::vector<u32> tv;
+  tv.reserve(repetition * lut_len);
+  for (size_t v = 0; v < lut_len; ++v)
+    for (size_t r = 0; r < repetition; ++r) tv.push_back(lut[v]);
+  for (size_t i = 0; i < repetition / 2; ++i)
+    if (tv[i] != 0) tv[i] = plaintext_modulus - tv[i];
+  const size_t mid = repetition / 2, len = tv.size();
+  for (size_t i = 0; i < len; ++i) out[i] = tv[(i + mid) % len];  // rotate_left(mid)
+  return TFHE_OK;
+}
+
+int check_tv_host(tfhe_context* ctx, const u32* tv, size_t words) {
+  // glwe.rs:144 assert!(*m < 1 << log_p)
+  if (ctx->params.log_p >= 32) return TFHE_OK;
+  const u32 lim = 1u << ctx->params.log_p;
+  for (size_t i = 0; i < words; ++i)
+    if (tv[i] >= lim)
+      return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "test vector value >= 2^log_p (glwe.rs:144)");
+  return TFHE_OK;
+}
+
+// Enqueue the whole PBS on device buffers: blind rotation (+ fused sample extract), key switch.
+int enqueue_bootstrap(tfhe_context* ctx, const u32* d_lwe_in, size_t batch, const u32* d_tv,
+                      size_t tv_count, u32* d_lwe_big, u32* d_lwe_out) {
+  if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+  HIP_TRY(ctx, launch::blind_rotate(ctx->stream, ctx->pbs, ctx->d_tw, d_lwe_in, batch, d_tv,
+                                    tv_count == 1 ? 0 : ctx->N, ctx->d_bsk, nullptr, d_lwe_big));
+  if (ctx->timing) {
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+  }
+  HIP_TRY(ctx, launch::key_switch(ctx->stream, ctx->ks, ctx->big_n, ctx->params.lwe_dimension,
+                                  d_lwe_big, batch, ctx->d_ksk, d_lwe_out));
+  if (ctx->timing) {
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    ctx->ev_valid_br = ctx->ev_valid_ks = true;
+  }
+  return TFHE_OK;
+}
+
+int check_batch_args(tfhe_context* ctx, const void* a, const void* b, const void* c, size_t batch,
+                     size_t tv_count) {
+  if (!a || !b || !c) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer");
+  if (batch == 0) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "empty batch");
+  if (tv_count != 1 && tv_count != batch)
+    return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "tv_count must be 1 or batch");
+  return TFHE_OK;
+}
+
+size_t ggsw_words(const tfhe_context* ctx) {
+  return (size_t)ctx->R * (ctx->params.glwe_dimension + 1) * ctx->N;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* tfhe_version(void) { return "tfhe-research_amd 0.1 (gfx950, goldilocks-ntt)"; }
+
+const char* tfhe_status_string(int status) {
+  switch (status) {
+    case TFHE_OK: return "ok";
+    case TFHE_ERR_INVALID_PARAMS: return "invalid parameter set";
+    case TFHE_ERR_UNSUPPORTED: return "unsupported shape";
+    case TFHE_ERR_NO_KEY: return "bootstrapping key not loaded";
+    case TFHE_ERR_HIP: return "HIP runtime error";
+    case TFHE_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case TFHE_ERR_NO_DEVICE: return "no GPU device (this library has no CPU path)";
+    case TFHE_ERR_EXACTNESS: return "parameter set exceeds the exact-NTT bound";
+    default: return "unknown status";
+  }
+}
+
+void tfhe_params_default(tfhe_params* p, int cfg_test) {
+  p->glwe_dimension = 2;
+  p->glwe_poly_degree = 9;
+  p->lwe_dimension = cfg_test ? 4 : 722;
+  p->padding_bits = 1;
+  p->log_p = 2;
+  p->log_q = 32;
+  p->ks_decomposer = {4, 5, 32};
+  p->pbs_decomposer = {4, 6, 32};
+}
+
+int tfhe_params_validate(const tfhe_params* p) {
+  if (!p) return TFHE_ERR_INVALID_ARGUMENT;
+  if (p->log_q != 32) return TFHE_ERR_INVALID_PARAMS;
+  if (decomposer_validate(p->pbs_decomposer) || decomposer_validate(p->ks_decomposer))
+    return TFHE_ERR_INVALID_PARAMS;
+  if (p->glwe_poly_degree == 0 || p->glwe_poly_degree + 1 >= 32) return TFHE_ERR_INVALID_PARAMS;
+  if (p->log_p + p->padding_bits > 32) return TFHE_ERR_INVALID_PARAMS;  // glwe.rs:145
+  if (p->log_p > p->glwe_poly_degree) return TFHE_ERR_INVALID_PARAMS;   // test_vector.rs:46
+  if (p->lwe_dimension == 0 || p->glwe_dimension == 0) return TFHE_ERR_INVALID_PARAMS;
+  return TFHE_OK;
+}
+
+const char* tfhe_last_error(const tfhe_context* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int tfhe_context_create(const tfhe_params* params, int device, tfhe_context** out) {
+  if (!params || !out) return TFHE_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  int st = tfhe_params_validate(params);
+  if (st != TFHE_OK) return st;
+  if (!launch::shape_supported(params->glwe_poly_degree, params->glwe_dimension))
+    return TFHE_ERR_UNSUPPORTED;
+  // exactness of the integer convolution in F_p: R * N * max|digit| * 2^32 < p/2 ~ 2^63
+  {
+    const double bits = std::log2((double)(params->glwe_dimension + 1) * params->pbs_decomposer.levels) +
+                        params->glwe_poly_degree + params->pbs_decomposer.log_base + 32.0;
+    if (bits >= 62.0) return TFHE_ERR_EXACTNESS;
+  }
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count)
+    return TFHE_ERR_NO_DEVICE;
+
+  tfhe_context* ctx = new (std::nothrow) tfhe_context();
+  if (!ctx) return TFHE_ERR_HIP;
+  ctx->params = *params;
+  ctx->device = device;
+  ctx->N = 1u << params->glwe_poly_degree;
+  ctx->R = (params->glwe_dimension + 1) * params->pbs_decomposer.levels;
+  ctx->big_n = ctx->N * params->glwe_dimension;  // lib.rs:60
+
+  ctx->pbs.n = params->lwe_dimension;
+  ctx->pbs.k = params->glwe_dimension;
+  ctx->pbs.log_n = params->glwe_poly_degree;
+  ctx->pbs.tv_shift = 32 - params->log_p - params->padding_bits;
+  ctx->pbs.log_base = params->pbs_decomposer.log_base;
+  ctx->pbs.levels = params->pbs_decomposer.levels;
+  ctx->pbs.ignored_bits = 32 - ctx->pbs.log_base * ctx->pbs.levels;
+  ctx->pbs.first_shift = ctx->pbs.log_base * (32 / ctx->pbs.log_base - ctx->pbs.levels);
+  ctx->ks.log_base = params->ks_decomposer.log_base;
+  ctx->ks.levels = params->ks_decomposer.levels;
+  ctx->ks.ignored_bits = 32 - ctx->ks.log_base * ctx->ks.levels;
+  ctx->ks.first_shift = ctx->ks.log_base * (32 / ctx->ks.log_base - ctx->ks.levels);
+
+  auto bail = [&](hipError_t e, const char* what) {
+    std::fprintf(stderr, "tfhe_context_create: %s: %s\n", what, hipGetErrorString(e));
+    tfhe_context_destroy(ctx);
+    return TFHE_ERR_HIP;
+  };
+  hipError_t e;
+  if ((e = hipSetDevice(device)) != hipSuccess) return bail(e, "hipSetDevice");
+  if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
+    return bail(e, "hipStreamCreate");
+  ctx->own_stream = true;
+  for (auto& ev : ctx->ev)
+    if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e, "hipEventCreate");
+
+  std::vector<u64> tw(ctx->N);
+  ntt_fill_twiddles((int)params->glwe_poly_degree, tw.data());
+  if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->d_tw), ctx->N * sizeof(u64))) != hipSuccess)
+    return bail(e, "hipMalloc twiddles");
+  if ((e = hipMemcpy(ctx->d_tw, tw.data(), ctx->N * sizeof(u64), hipMemcpyHostToDevice)) != hipSuccess)
+    return bail(e, "hipMemcpy twiddles");
+  if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->d_tv_gate), ctx->N * sizeof(u32))) != hipSuccess)
+    return bail(e, "hipMalloc gate tv");
+  *out = ctx;
+  return TFHE_OK;
+}
+
+void tfhe_context_destroy(tfhe_context* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  void* ptrs[] = {ctx->d_tw,     ctx->d_bsk,    ctx->d_ksk,    ctx->d_lwe_in, ctx->d_lwe_in2,
+                  ctx->d_lwe_big, ctx->d_lwe_out, ctx->d_glwe_a, ctx->d_glwe_b, ctx->d_glwe_c,
+                  ctx->d_tv,     ctx->d_tv_gate, ctx->d_misc,   ctx->d_ggsw_tmp, ctx->d_ggsw_raw};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  for (auto& ev : ctx->ev)
+    if (ev) (void)hipEventDestroy(ev);
+  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int tfhe_context_set_stream(tfhe_context* ctx, void* hip_stream) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  if (ctx->stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->own_stream && ctx->stream) HIP_TRY(ctx, hipStreamDestroy(ctx->stream));
+  if (hip_stream) {
+    ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    ctx->own_stream = false;
+  } else {
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    ctx->own_stream = true;
+  }
+  return TFHE_OK;
+}
+
+int tfhe_context_synchronize(tfhe_context* ctx) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return TFHE_OK;
+}
+
+int tfhe_context_reserve(tfhe_context* ctx, size_t max_batch) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  if (max_batch == 0) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "max_batch == 0");
+  return reserve(ctx, max_batch);
+}
+
+int tfhe_context_set_timing(tfhe_context* ctx, int enable) {
+  if (!ctx) return TFHE_ERR_INVALID_ARGUMENT;
+  ctx->timing = enable != 0;
+  ctx->ev_valid_br = ctx->ev_valid_ks = false;
+  return TFHE_OK;
+}
+
+int tfhe_last_kernel_ms(tfhe_context* ctx, float* blind_rotate_ms, float* key_switch_ms) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  if (blind_rotate_ms) *blind_rotate_ms = -1.0f;
+  if (key_switch_ms) *key_switch_ms = -1.0f;
+  if (ctx->ev_valid_br && blind_rotate_ms) {
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev[1]));
+    HIP_TRY(ctx, hipEventElapsedTime(blind_rotate_ms, ctx->ev[0], ctx->ev[1]));
+  }
+  if (ctx->ev_valid_ks && key_switch_ms) {
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev[3]));
+    HIP_TRY(ctx, hipEventElapsedTime(key_switch_ms, ctx->ev[2], ctx->ev[3]));
+  }
+  return TFHE_OK;
+}
+
+// ---------------------------------------------------------------------------------- keys
+static int load_key_common(tfhe_context* ctx, const u32* d_bsk_raw, const u32* d_ksk_raw,
+                           bool ksk_needs_copy) {
+  const size_t bsk_polys = (size_t)ctx->params.lwe_dimension * ctx->R * (ctx->params.glwe_dimension + 1);
+  const size_t ksk_words = (size_t)ctx->big_n * ctx->ks.levels * ((size_t)ctx->params.lwe_dimension + 1);
+  if (!ctx->d_bsk)
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_bsk), bsk_polys * ctx->N * sizeof(u64)));
+  if (!ctx->d_ksk)
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_ksk), ksk_words * sizeof(u32)));
+  HIP_TRY(ctx, launch::bsk_prepare(ctx->stream, ctx->pbs.log_n, ctx->d_tw, d_bsk_raw, bsk_polys, ctx->d_bsk));
+  if (ksk_needs_copy)
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_ksk, d_ksk_raw, ksk_words * sizeof(u32),
+                                hipMemcpyDeviceToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->have_key = true;
+  return TFHE_OK;
+}
+
+int tfhe_load_bootstrapping_key(tfhe_context* ctx, const uint32_t* bsk, const uint32_t* ksk) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  if (!bsk || !ksk) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null key pointer");
+  const size_t bsk_words = (size_t)ctx->params.lwe_dimension * ggsw_words(ctx);
+  const size_t ksk_words = (size_t)ctx->big_n * ctx->ks.levels * ((size_t)ctx->params.lwe_dimension + 1);
+  u32* d_raw = nullptr;
+  HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d_raw), bsk_words * sizeof(u32)));
+  hipError_t e = hipMemcpy(d_raw, bsk, bsk_words * sizeof(u32), hipMemcpyHostToDevice);
+  if (e == hipSuccess && !ctx->d_ksk)
+    e = hipMalloc(reinterpret_cast<void**>(&ctx->d_ksk), ksk_words * sizeof(u32));
+  if (e == hipSuccess) e = hipMemcpy(ctx->d_ksk, ksk, ksk_words * sizeof(u32), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    (void)hipFree(d_raw);
+    return hip_fail(ctx, e, "key upload");
+  }
+  st = load_key_common(ctx, d_raw, nullptr, false);
+  (void)hipFree(d_raw);
+  return st;
+}
+
+int tfhe_load_bootstrapping_key_device(tfhe_context* ctx, const uint32_t* bsk, const uint32_t* ksk) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  if (!bsk || !ksk) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null key pointer");
+  return load_key_common(ctx, bsk, ksk, true);
+}
+
+// ---------------------------------------------------------------------------------- bootstrap
+int tfhe_bootstrap_batch_device(tfhe_context* ctx, const uint32_t* lwe_in, size_t batch,
+                                const uint32_t* tv, size_t tv_count, uint32_t* lwe_out) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  if ((st = check_batch_args(ctx, lwe_in, tv, lwe_out, batch, tv_count))) return st;
+  if (!ctx->have_key) return fail(ctx, TFHE_ERR_NO_KEY, "load the bootstrapping key first");
+  if ((st = reserve(ctx, batch))) return st;
+  return enqueue_bootstrap(ctx, lwe_in, batch, tv, tv_count, ctx->d_lwe_big, lwe_out);
+}
+
+int tfhe_bootstrap_batch(tfhe_context* ctx, const uint32_t* lwe_in, size_t batch, const uint32_t* tv,
+                         size_t tv_count, uint32_t* lwe_out) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  if ((st = check_batch_args(ctx, lwe_in, tv, lwe_out, batch, tv_count))) return st;
+  if (!ctx->have_key) return fail(ctx, TFHE_ERR_NO_KEY, "load the bootstrapping key first");
+  if ((st = check_tv_host(ctx, tv, tv_count * ctx->N))) return st;
+  if ((st = reserve(ctx, batch))) return st;
+  const size_t n1 = (size_t)ctx->params.lwe_dimension + 1;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_lwe_in, lwe_in, batch * n1 * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_tv, tv, tv_count * ctx->N * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+  if ((st = enqueue_bootstrap(ctx, ctx->d_lwe_in, batch, ctx->d_tv, tv_count, ctx->d_lwe_big, ctx->d_lwe_out)))
+    return st;
+  HIP_TRY(ctx, hipMemcpyAsync(lwe_out, ctx->d_lwe_out, batch * n1 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return TFHE_OK;
+}
+
+int tfhe_blind_rotate_batch_device(tfhe_context* ctx, const uint32_t* lwe_in, size_t batch,
+                                   const uint32_t* tv, size_t tv_count, uint32_t* glwe_out) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  if ((st = check_batch_args(ctx, lwe_in, tv, glwe_out, batch, tv_count))) return st;
+  if (!ctx->have_key) return fail(ctx, TFHE_ERR_NO_KEY, "load the bootstrapping key first");
+  if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+  HIP_TRY(ctx, launch::blind_rotate(ctx->stream, ctx->pbs, ctx->d_tw, lwe_in, batch, tv,
+                                    tv_count == 1 ? 0 : ctx->N, ctx->d_bsk, glwe_out, nullptr));
+  if (ctx->timing) {
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    ctx->ev_valid_br = true;
+    ctx->ev_valid_ks = false;
+  }
+  return TFHE_OK;
+}
+
+int tfhe_blind_rotate_batch(tfhe_context* ctx, const uint32_t* lwe_in, size_t batch,
+                            const uint32_t* tv, size_t tv_count, uint32_t* glwe_out) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  if ((st = check_batch_args(ctx, lwe_in, tv, glwe_out, batch, tv_count))) return st;
+  if (!ctx->have_key) return fail(ctx, TFHE_ERR_NO_KEY, "load the bootstrapping key first");
+  if ((st = check_tv_host(ctx, tv, tv_count * ctx->N))) return st;
+  if ((st = reserve(ctx, batch))) return st;
+  const size_t n1 = (size_t)ctx->params.lwe_dimension + 1;
+  const size_t glwe = (size_t)(ctx->params.glwe_dimension + 1) * ctx->N;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_lwe_in, lwe_in, batch * n1 * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_tv, tv, tv_count * ctx->N * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+  if ((st = tfhe_blind_rotate_batch_device(ctx, ctx->d_lwe_in, batch, ctx->d_tv, tv_count, ctx->d_glwe_a)))
+    return st;
+  HIP_TRY(ctx, hipMemcpyAsync(glwe_out, ctx->d_glwe_a, batch * glwe * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return TFHE_OK;
+}
+
+int tfhe_sample_extract_batch(tfhe_context* ctx, const uint32_t* glwe, size_t batch,
+                              size_t sample_index, uint32_t* lwe_out) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  if (!glwe || !lwe_out || batch == 0) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer / empty batch");
+  if (sample_index >= ctx->N)  // assert!(sample_index < degree), bootstrapping.rs:127
+    return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "sample_index >= N (bootstrapping.rs:127)");
+  if ((st = reserve(ctx, batch))) return st;
+  const size_t glwe_w = (size_t)(ctx->params.glwe_dimension + 1) * ctx->N;
+  const size_t out_w = (size_t)ctx->big_n + 1;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_glwe_a, glwe, batch * glwe_w * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, launch::sample_extract(ctx->stream, ctx->pbs.log_n, ctx->pbs.k, ctx->d_glwe_a, batch,
+                                      (u32)sample_index, ctx->d_lwe_big));
+  HIP_TRY(ctx, hipMemcpyAsync(lwe_out, ctx->d_lwe_big, batch * out_w * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return TFHE_OK;
+}
+
+int tfhe_key_switch_batch_device(tfhe_context* ctx, const uint32_t* lwe_in, size_t batch,
+                                 uint32_t* lwe_out) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  if (!lwe_in || !lwe_out || batch == 0) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer / empty batch");
+  if (!ctx->have_key) return fail(ctx, TFHE_ERR_NO_KEY, "load the bootstrapping key first");
+  if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+  HIP_TRY(ctx, launch::key_switch(ctx->stream, ctx->ks, ctx->big_n, ctx->params.lwe_dimension, lwe_in,
+                                  batch, ctx->d_ksk, lwe_out));
+  if (ctx->timing) {
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    ctx->ev_valid_ks = true;
+    ctx->ev_valid_br = false;
+  }
+  return TFHE_OK;
+}
+
+int tfhe_key_switch_batch(tfhe_context* ctx, const uint32_t* lwe_in, size_t batch, uint32_t* lwe_out) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  if (!lwe_in || !lwe_out || batch == 0) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer / empty batch");
+  if (!ctx->have_key) return fail(ctx, TFHE_ERR_NO_KEY, "load the bootstrapping key first");
+  if ((st = reserve(ctx, batch))) return st;
+  const size_t in_w = (size_t)ctx->big_n + 1, out_w = (size_t)ctx->params.lwe_dimension + 1;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_lwe_big, lwe_in, batch * in_w * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+  if ((st = tfhe_key_switch_batch_device(ctx, ctx->d_lwe_big, batch, ctx->d_lwe_out))) return st;
+  HIP_TRY(ctx, hipMemcpyAsync(lwe_out, ctx->d_lwe_out, batch * out_w * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return TFHE_OK;
+}
+
+// ---------------------------------------------------------------------------------- ggsw.rs
+int tfhe_prepare_ggsw_device(tfhe_context* ctx, const uint32_t* ggsw, size_t ggsw_count,
+                             uint64_t* ggsw_prepared) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  if (!ggsw || !ggsw_prepared || ggsw_count == 0) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer / zero count");
+  const size_t polys = ggsw_count * ctx->R * (ctx->params.glwe_dimension + 1);
+  HIP_TRY(ctx, launch::bsk_prepare(ctx->stream, ctx->pbs.log_n, ctx->d_tw, ggsw, polys,
+                                   reinterpret_cast<u64*>(ggsw_prepared)));
+  return TFHE_OK;
+}
+
+int tfhe_external_product_prepared_device(tfhe_context* ctx, const uint64_t* ggsw_prepared,
+                                          size_t ggsw_count, const uint32_t* glwe_in, size_t batch,
+                                          uint32_t* glwe_out) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  if (!ggsw_prepared || !glwe_in || !glwe_out || batch == 0)
+    return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer / empty batch");
+  if (ggsw_count != 1 && ggsw_count != batch)
+    return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "ggsw_count must be 1 or batch");
+  if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+  HIP_TRY(ctx, launch::external_product(ctx->stream, ctx->pbs, ctx->d_tw,
+                                        reinterpret_cast<const u64*>(ggsw_prepared),
+                                        ggsw_count == 1 ? 0 : ggsw_words(ctx), glwe_in, nullptr, nullptr,
+                                        batch, glwe_out));
+  if (ctx->timing) {
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    ctx->ev_valid_br = true;
+    ctx->ev_valid_ks = false;
+  }
+  return TFHE_OK;
+}
+
+static int upload_and_prepare_ggsw(tfhe_context* ctx, const u32* ggsw, size_t ggsw_count) {
+  const size_t words = ggsw_count * ggsw_words(ctx);
+  int st;
+  if ((st = ensure(ctx, &ctx->d_ggsw_raw, &ctx->ggsw_raw_words, words))) return st;
+  if ((st = ensure(ctx, &ctx->d_ggsw_tmp, &ctx->ggsw_tmp_words, words))) return st;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_ggsw_raw, ggsw, words * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+  return tfhe_prepare_ggsw_device(ctx, ctx->d_ggsw_raw, ggsw_count, reinterpret_cast<uint64_t*>(ctx->d_ggsw_tmp));
+}
+
+int tfhe_external_product_batch(tfhe_context* ctx, const uint32_t* ggsw, size_t ggsw_count,
+                                const uint32_t* glwe_in, size_t batch, uint32_t* glwe_out) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  if (!ggsw || !glwe_in || !glwe_out || batch == 0) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer / empty batch");
+  if (ggsw_count != 1 && ggsw_count != batch) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "ggsw_count must be 1 or batch");
+  if ((st = reserve(ctx, batch))) return st;
+  if ((st = upload_and_prepare_ggsw(ctx, ggsw, ggsw_count))) return st;
+  const size_t glwe = (size_t)(ctx->params.glwe_dimension + 1) * ctx->N;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_glwe_a, glwe_in, batch * glwe * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+  if ((st = tfhe_external_product_prepared_device(ctx, reinterpret_cast<uint64_t*>(ctx->d_ggsw_tmp), ggsw_count,
+                                                  ctx->d_glwe_a, batch, ctx->d_glwe_b)))
+    return st;
+  HIP_TRY(ctx, hipMemcpyAsync(glwe_out, ctx->d_glwe_b, batch * glwe * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return TFHE_OK;
+}
+
+int tfhe_cmux_batch(tfhe_context* ctx, const uint32_t* ggsw, size_t ggsw_count, const uint32_t* ct0,
+                    uint32_t* ct1, size_t batch, uint32_t* glwe_out) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  if (!ggsw || !ct0 || !ct1 || !glwe_out || batch == 0) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer / empty batch");
+  if (ggsw_count != 1 && ggsw_count != batch) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "ggsw_count must be 1 or batch");
+  if ((st = reserve(ctx, batch))) return st;
+  if ((st = upload_and_prepare_ggsw(ctx, ggsw, ggsw_count))) return st;
+  const size_t glwe = (size_t)(ctx->params.glwe_dimension + 1) * ctx->N;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_glwe_a, ct0, batch * glwe * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_glwe_b, ct1, batch * glwe * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, launch::external_product(ctx->stream, ctx->pbs, ctx->d_tw, ctx->d_ggsw_tmp,
+                                        ggsw_count == 1 ? 0 : ggsw_words(ctx), nullptr, ctx->d_glwe_b,
+                                        ctx->d_glwe_a, batch, ctx->d_glwe_c));
+  HIP_TRY(ctx, hipMemcpyAsync(glwe_out, ctx->d_glwe_c, batch * glwe * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ct1, ctx->d_glwe_b, batch * glwe * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return TFHE_OK;
+}
+
+// ---------------------------------------------------------------------------------- small ops
+int tfhe_decompose(tfhe_context* ctx, int which, const uint32_t* values, size_t count, uint32_t* digits_out) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  if (!values || !digits_out || count == 0) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer / zero count");
+  if (which != TFHE_DECOMPOSER_PBS && which != TFHE_DECOMPOSER_KS) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "bad decomposer selector");
+  const tfhe_decomposer_params& d = which == TFHE_DECOMPOSER_PBS ? ctx->params.pbs_decomposer : ctx->params.ks_decomposer;
+  const size_t in_b = count * sizeof(u32), out_b = count * d.levels * sizeof(u32);
+  if ((st = ensure_misc(ctx, in_b + out_b))) return st;
+  u32* d_in = reinterpret_cast<u32*>(ctx->d_misc);
+  u32* d_out = d_in + count;
+  HIP_TRY(ctx, hipMemcpyAsync(d_in, values, in_b, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, launch::decompose_words(ctx->stream, d.log_base, d.levels, d_in, count, d_out));
+  HIP_TRY(ctx, hipMemcpyAsync(digits_out, d_out, out_b, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return TFHE_OK;
+}
+
+int tfhe_decompose_glwe_batch(tfhe_context* ctx, const uint32_t* glwe, size_t batch, uint32_t* digits_out) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  if (!glwe || !digits_out || batch == 0) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer / empty batch");
+  const u32 polys = ctx->params.glwe_dimension + 1;
+  const size_t in_w = batch * polys * ctx->N, out_w = in_w * ctx->pbs.levels;
+  if ((st = ensure_misc(ctx, (in_w + out_w) * sizeof(u32)))) return st;
+  u32* d_in = reinterpret_cast<u32*>(ctx->d_misc);
+  u32* d_out = d_in + in_w;
+  HIP_TRY(ctx, hipMemcpyAsync(d_in, glwe, in_w * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, launch::decompose_glwe(ctx->stream, ctx->pbs.log_base, ctx->pbs.levels, polys, ctx->N, d_in, batch, d_out));
+  HIP_TRY(ctx, hipMemcpyAsync(digits_out, d_out, out_w * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return TFHE_OK;
+}
+
+int tfhe_switch_modulus(tfhe_context* ctx, const uint32_t* values, size_t count, uint32_t log_from,
+                        uint32_t log_to, uint32_t* out) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  if (!values || !out || count == 0) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer / zero count");
+  // `1 << (log_from - log_to)` and `1 << log_to` on u32 (utils.rs:27-28)
+  if (log_from > 32 || log_to > log_from || log_from - log_to >= 32 || log_to >= 32)
+    return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "switch_modulus shift out of range");
+  if ((st = ensure_misc(ctx, 2 * count * sizeof(u32)))) return st;
+  u32* d_in = reinterpret_cast<u32*>(ctx->d_misc);
+  u32* d_out = d_in + count;
+  HIP_TRY(ctx, hipMemcpyAsync(d_in, values, count * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, launch::switch_modulus(ctx->stream, d_in, count, log_from, log_to, d_out));
+  HIP_TRY(ctx, hipMemcpyAsync(out, d_out, count * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return TFHE_OK;
+}
+
+int tfhe_glwe_mul_monomial_batch(tfhe_context* ctx, const uint32_t* glwe_in, size_t batch,
+                                 const int64_t* monomial_index, uint32_t* glwe_out) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  if (!glwe_in || !monomial_index || !glwe_out || batch == 0) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer / empty batch");
+  const u32 polys = ctx->params.glwe_dimension + 1;
+  const size_t w = batch * polys * ctx->N;
+  const size_t idx_b = ((batch * sizeof(i64) + 15) / 16) * 16;
+  if ((st = ensure_misc(ctx, idx_b + 2 * w * sizeof(u32)))) return st;
+  i64* d_idx = reinterpret_cast<i64*>(ctx->d_misc);
+  u32* d_in = reinterpret_cast<u32*>(reinterpret_cast<char*>(ctx->d_misc) + idx_b);
+  u32* d_out = d_in + w;
+  HIP_TRY(ctx, hipMemcpyAsync(d_idx, monomial_index, batch * sizeof(i64), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_in, glwe_in, w * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, launch::glwe_mul_monomial(ctx->stream, ctx->pbs.log_n, polys, d_in, batch, d_idx, d_out));
+  HIP_TRY(ctx, hipMemcpyAsync(glwe_out, d_out, w * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return TFHE_OK;
+}
+
+// ---------------------------------------------------------------------------------- test vectors / gates
+int tfhe_construct_test_from_lut(const tfhe_params* params, const uint32_t* lut, size_t lut_len, uint32_t* out) {
+  if (!params || !lut || !out) return TFHE_ERR_INVALID_ARGUMENT;
+  int st = tfhe_params_validate(params);
+  if (st) return st;
+  return test_from_lut(params, lut, lut_len, out);
+}
+
+int tfhe_construct_test_vector_boolean(const tfhe_params* params, const uint32_t truth[4], uint32_t* out) {
+  if (!params || !truth || !out) return TFHE_ERR_INVALID_ARGUMENT;
+  int st = tfhe_params_validate(params);
+  if (st) return st;
+  const u32 pm = 1u << params->log_p;
+  std::vector<u32> lut(pm);
+  for (u32 i = 0; i < pm; ++i) lut[i] = truth[(((i >> 1) & 1u) << 1) | (i & 1u)];  // test_vector.rs:16
+  return test_from_lut(params, lut.data(), pm, out);
+}
+
+int tfhe_gate_batch_device(tfhe_context* ctx, const uint32_t truth[4], const uint32_t* ct0,
+                           const uint32_t* ct1, size_t batch, uint32_t* lwe_out) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  if (!truth || !ct0 || !ct1 || !lwe_out || batch == 0) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer / empty batch");
+  if (!ctx->have_key) return fail(ctx, TFHE_ERR_NO_KEY, "load the bootstrapping key first");
+  std::vector<u32> tv(ctx->N);
+  if ((st = tfhe_construct_test_vector_boolean(&ctx->params, truth, tv.data()))) return st;
+  if ((st = check_tv_host(ctx, tv.data(), ctx->N))) return st;
+  if ((st = reserve(ctx, batch))) return st;
+  const size_t words = batch * ((size_t)ctx->params.lwe_dimension + 1);
+  // pageable host -> device copy is staged by the runtime before it returns
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_tv_gate, tv.data(), ctx->N * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, launch::lwe_gate_input(ctx->stream, ct0, ct1, words, ctx->d_lwe_in2));
+  return enqueue_bootstrap(ctx, ctx->d_lwe_in2, batch, ctx->d_tv_gate, 1, ctx->d_lwe_big, lwe_out);
+}
+
+int tfhe_gate_batch(tfhe_context* ctx, const uint32_t truth[4], const uint32_t* ct0,
+                    const uint32_t* ct1, size_t batch, uint32_t* lwe_out) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  if (!truth || !ct0 || !ct1 || !lwe_out || batch == 0) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer / empty batch");
+  if (!ctx->have_key) return fail(ctx, TFHE_ERR_NO_KEY, "load the bootstrapping key first");
+  if ((st = reserve(ctx, batch))) return st;
+  const size_t words = batch * ((size_t)ctx->params.lwe_dimension + 1);
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_lwe_in, ct0, words * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_lwe_out, ct1, words * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+  if ((st = tfhe_gate_batch_device(ctx, truth, ctx->d_lwe_in, ctx->d_lwe_out, batch, ctx->d_lwe_out))) return st;
+  HIP_TRY(ctx, hipMemcpyAsync(lwe_out, ctx->d_lwe_out, words * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return TFHE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,486 @@
+// kernels.hip -- gfx950 (CDNA4 / MI355X) kernels of the TFHE bootstrapping hot path.
+//
+// Execution shape: ONE 64-lane wavefront per LWE sample / per polynomial (pbs_wave.h).  A
+// workgroup is just a bundle of independent waves that share the twiddle table in LDS; after
+// the table is staged there is no workgroup barrier anywhere, only wave-local LDS ordering.
+//
+// LDS layout of a per-wave kernel (dynamic, base 16-B aligned, no static LDS in front of it):
+//   [ twiddles psi_rev : N u64 ][ wave 0: scratch N u64 | acc (K+1)*N u32 ][ wave 1: ... ] ...
+#include "launch.h"
+
+namespace tfhe {
+namespace {
+
+struct DeviceWave {
+  u64* scratch_;
+  u32* acc_;
+  const u64* tw_;
+  __device__ __forceinline__ int lane() const { return (int)(threadIdx.x & 63u); }
+  // Orders this wave's LDS stores before its later LDS loads.  All 64 lanes run in lockstep and
+  // the LDS pipeline is in-order per wave, so only the compiler has to be fenced.
+  __device__ __forceinline__ void sync() const {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  __device__ __forceinline__ u64* scratch() const { return scratch_; }
+  __device__ __forceinline__ u32* acc() const { return acc_; }
+  __device__ __forceinline__ const u64* twiddles() const { return tw_; }
+  __device__ __forceinline__ u32 uniform(u32 v) const { return __builtin_amdgcn_readfirstlane(v); }
+};
+
+template <int LOGN, int K>
+struct WaveCfg {
+  static constexpr int N = 1 << LOGN;
+  // waves per workgroup: bounded by 160 KiB LDS per CU and the register budget
+  static constexpr int kWaves = (LOGN == 11) ? 2 : 4;
+  static constexpr int kMinWavesPerSimd = (LOGN == 11) ? 1 : 2;
+  static constexpr size_t kWaveLds = (size_t)N * 8 + (size_t)(K + 1) * N * 4;
+  static constexpr size_t kLds = (size_t)N * 8 + kWaves * kWaveLds;
+};
+
+template <int LOGN, int K>
+__device__ __forceinline__ DeviceWave make_wave(unsigned char* smem, const u64* tw_global) {
+  using C = WaveCfg<LOGN, K>;
+  u64* tw = reinterpret_cast<u64*>(smem);
+  for (int i = threadIdx.x; i < C::N; i += blockDim.x) tw[i] = tw_global[i];
+  __syncthreads();
+  const int wave = (int)(threadIdx.x >> 6);
+  unsigned char* base = smem + (size_t)C::N * 8 + (size_t)wave * C::kWaveLds;
+  DeviceWave w;
+  w.tw_ = tw;
+  w.scratch_ = reinterpret_cast<u64*>(base);
+  w.acc_ = reinterpret_cast<u32*>(base + (size_t)C::N * 8);
+  return w;
+}
+
+extern __shared__ __attribute__((aligned(16))) unsigned char g_smem[];
+
+// ------------------------------------------------------------------------------ bsk_prepare
+template <int LOGN>
+__global__ void __launch_bounds__(256) bsk_prepare_kernel(const u64* __restrict__ tw,
+                                                         const u32* __restrict__ polys,
+                                                         size_t poly_count, u64* __restrict__ spectra,
+                                                         u64 n_inv) {
+  constexpr int N = 1 << LOGN;
+  u64* twl = reinterpret_cast<u64*>(g_smem);
+  for (int i = threadIdx.x; i < N; i += blockDim.x) twl[i] = tw[i];
+  __syncthreads();
+  const int wave = (int)(threadIdx.x >> 6);
+  const size_t poly = (size_t)blockIdx.x * (blockDim.x >> 6) + wave;
+  if (poly >= poly_count) return;
+  DeviceWave w;
+  w.tw_ = twl;
+  w.scratch_ = reinterpret_cast<u64*>(g_smem + (size_t)N * 8 + (size_t)wave * N * 8);
+  w.acc_ = nullptr;
+  bsk_prepare_wave<LOGN>(w, polys + poly * N, spectra + poly * N, n_inv);
+}
+
+// ------------------------------------------------------------------------------ blind rotation
+template <int LOGN, int K>
+__global__ void __launch_bounds__((WaveCfg<LOGN, K>::kWaves * 64), (WaveCfg<LOGN, K>::kMinWavesPerSimd))
+blind_rotate_kernel(PbsParams P, const u64* __restrict__ tw, const u32* __restrict__ lwe_in,
+                    size_t batch, const u32* __restrict__ tv, size_t tv_stride,
+                    const u64* __restrict__ bsk, u32* __restrict__ glwe_out,
+                    u32* __restrict__ lwe_extracted) {
+  using C = WaveCfg<LOGN, K>;
+  constexpr int N = C::N;
+  constexpr int E = NttShape<LOGN>::kE;
+  DeviceWave w = make_wave<LOGN, K>(g_smem, tw);
+  const size_t sample = (size_t)blockIdx.x * C::kWaves + (threadIdx.x >> 6);
+  if (sample >= batch) return;
+
+  blind_rotate_wave<LOGN, K>(w, P, lwe_in + sample * (P.n + 1), tv + sample * tv_stride, bsk);
+
+  const int lane = w.lane();
+  if (glwe_out) {
+    u32* dst = glwe_out + sample * (size_t)(K + 1) * N;
+#pragma unroll
+    for (int p = 0; p <= K; ++p)
+#pragma unroll
+      for (int r = 0; r < E; ++r) dst[p * N + r * 64 + lane] = w.acc()[p * N + r * 64 + lane];
+  }
+  if (lwe_extracted) sample_extract_wave<LOGN, K>(w, lwe_extracted + sample * ((size_t)K * N + 1));
+}
+
+// ------------------------------------------------------------------------------ external product
+template <int LOGN, int K>
+__global__ void __launch_bounds__((WaveCfg<LOGN, K>::kWaves * 64), (WaveCfg<LOGN, K>::kMinWavesPerSimd))
+external_product_kernel(PbsParams P, const u64* __restrict__ tw, const u64* __restrict__ ggsw,
+                        size_t ggsw_stride_words, const u32* glwe_in, u32* ct1_inout,
+                        const u32* cmux_ct0, size_t batch, u32* glwe_out) {
+  using C = WaveCfg<LOGN, K>;
+  constexpr int N = C::N;
+  DeviceWave w = make_wave<LOGN, K>(g_smem, tw);
+  const size_t sample = (size_t)blockIdx.x * C::kWaves + (threadIdx.x >> 6);
+  if (sample >= batch) return;
+  const size_t ct = sample * (size_t)(K + 1) * N;
+  const u64* g = ggsw + sample * ggsw_stride_words;
+  u32* dst = glwe_out + ct;
+  if (cmux_ct0 == nullptr) {
+    const u32* in = glwe_in + ct;
+    auto src = [&](int p, int j) -> u32 { return in[p * N + j]; };
+    auto out = [&](int p, int j, u32 v) { dst[p * N + j] = v; };
+    external_product_wave<LOGN, K>(w, P, g, src, out);
+  } else {
+    const u32* c0 = cmux_ct0 + ct;
+    u32* c1 = ct1_inout + ct;
+    // *glwe_ciphertext1 -= glwe_ciphertext0 (ggsw.rs:171): each coefficient is read and written
+    // by the one lane that owns index j, so the in-place update is race free
+    auto src = [&](int p, int j) -> u32 {
+      const u32 d = c1[p * N + j] - c0[p * N + j];
+      c1[p * N + j] = d;
+      return d;
+    };
+    auto out = [&](int p, int j, u32 v) { dst[p * N + j] = v + c0[p * N + j]; };
+    external_product_wave<LOGN, K>(w, P, g, src, out);
+  }
+}
+
+// ------------------------------------------------------------------------------ key switch
+// out[b][c] = -sum_{i<big_n, l<levels} digit_l(lwe[b][i]) * ksk[i*levels + l][c];  out[b][n] += b
+// Tiled as a wrapping-u32 GEMM: a workgroup owns kKsSamples samples x 64 output columns and walks
+// the big_n*levels key rows in chunks; digits of the chunk are produced once into LDS.
+constexpr int kKsSamples = 32;     // samples per workgroup
+constexpr int kKsCols = 64;        // output columns per workgroup (one per lane)
+constexpr int kKsWords = 8;        // mask words decomposed per chunk
+constexpr int kKsPerThread = 8;    // samples per thread (kKsSamples / 4 waves)
+
+__global__ void __launch_bounds__(256) key_switch_kernel(KsParams Kp, u32 big_n, u32 n,
+                                                         const u32* __restrict__ lwe_in, size_t batch,
+                                                         const u32* __restrict__ ksk,
+                                                         u32* __restrict__ lwe_out) {
+  u32* dig = reinterpret_cast<u32*>(g_smem);  // [kKsWords*levels][kKsSamples]
+  const int tx = (int)(threadIdx.x & 63u);
+  const int ty = (int)(threadIdx.x >> 6);
+  const u32 col = blockIdx.x * kKsCols + tx;
+  const size_t s0 = (size_t)blockIdx.y * kKsSamples;
+  const u32 width = n + 1;
+  const u32 levels = Kp.levels;
+  const bool col_ok = col < width;
+
+  u32 acc[kKsPerThread];
+#pragma unroll
+  for (int s = 0; s < kKsPerThread; ++s) acc[s] = 0;
+
+  for (u32 w0 = 0; w0 < big_n; w0 += kKsWords) {
+    // 256 threads decompose 32 samples x 8 words: thread -> (sample = tid / 8, word = tid % 8)
+    {
+      const int sl = (int)(threadIdx.x >> 3);
+      const u32 wl = threadIdx.x & 7u;
+      const size_t sample = s0 + sl;
+      const u32 word = w0 + wl;
+      u32 v = 0;
+      if (sample < batch && word < big_n) v = lwe_in[sample * ((size_t)big_n + 1) + word];
+      v = round_value(v, Kp.ignored_bits);
+      u32 carry = 0;
+      for (u32 t = 0; t < levels; ++t) {  // LSB -> MSB, level index counts from the MSB
+        const u32 d = decompose_limb(v, Kp.first_shift + Kp.log_base * t, Kp.log_base, carry);
+        dig[(wl * levels + (levels - 1 - t)) * kKsSamples + sl] = d;
+      }
+    }
+    __syncthreads();
+    const u32 rows = ((big_n - w0 < (u32)kKsWords) ? (big_n - w0) : (u32)kKsWords) * levels;
+    const u32* krow = ksk + (size_t)w0 * levels * width + col;
+    for (u32 r = 0; r < rows; ++r) {
+      const u32 kv = col_ok ? krow[(size_t)r * width] : 0u;
+      const u32* d = dig + r * kKsSamples + ty * kKsPerThread;
+#pragma unroll
+      for (int s = 0; s < kKsPerThread; ++s) acc[s] += d[s] * kv;
+    }
+    __syncthreads();
+  }
+
+  if (!col_ok) return;
+#pragma unroll
+  for (int s = 0; s < kKsPerThread; ++s) {
+    const size_t sample = s0 + ty * kKsPerThread + s;
+    if (sample >= batch) continue;
+    u32 v = 0u - acc[s];
+    if (col == n) v += lwe_in[sample * ((size_t)big_n + 1) + big_n];
+    lwe_out[sample * width + col] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------ elementwise
+__global__ void decompose_words_kernel(u32 log_base, u32 levels, u32 ignored_bits, u32 first_shift,
+                                       const u32* __restrict__ values, size_t count,
+                                       u32* __restrict__ digits) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const u32 v = round_value(values[i], ignored_bits);
+    u32 carry = 0;
+    for (u32 t = 0; t < levels; ++t)
+      digits[i * levels + (levels - 1 - t)] = decompose_limb(v, first_shift + log_base * t, log_base, carry);
+  }
+}
+
+// glwe [batch][polys][N] -> digits [batch][polys*levels][N]
+__global__ void decompose_glwe_kernel(u32 log_base, u32 levels, u32 ignored_bits, u32 first_shift,
+                                      u32 polys, u32 n_coeff, const u32* __restrict__ glwe,
+                                      size_t total /* batch*polys*N */, u32* __restrict__ digits) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const size_t poly = i / n_coeff;  // global polynomial index = b*polys + p
+    const u32 j = (u32)(i % n_coeff);
+    const u32 v = round_value(glwe[i], ignored_bits);
+    u32 carry = 0;
+    for (u32 t = 0; t < levels; ++t)
+      digits[(poly * levels + (levels - 1 - t)) * n_coeff + j] =
+          decompose_limb(v, first_shift + log_base * t, log_base, carry);
+  }
+}
+
+__global__ void switch_modulus_kernel(const u32* __restrict__ values, size_t count, u32 log_from,
+                                      u32 log_to, u32* __restrict__ out) {
+  // utils.rs:13-33
+  const u32 sh = log_from - log_to;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+       i += (size_t)gridDim.x * blockDim.x) {
+    u32 v = values[i];
+    if (sh == 0) {
+      // divisor 1: rational = v, fractional = 0
+    } else {
+      v = (v >> sh) + ((v >> (sh - 1)) & 1u);
+    }
+    out[i] = (log_to >= 32) ? v : (v & ((1u << log_to) - 1u));
+  }
+}
+
+__global__ void glwe_mul_monomial_kernel(u32 log_n, u32 polys, const u32* __restrict__ glwe,
+                                         size_t total, const i64* __restrict__ monomial_index,
+                                         u32* __restrict__ out) {
+  const u32 N = 1u << log_n;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const size_t poly = i >> log_n;
+    const u32 j = (u32)(i & (N - 1));
+    // `monomial_index as usize % (2*n)` (utils.rs:186): two's complement residue mod 2N
+    const u32 m = (u32)((u64)monomial_index[poly / polys] & (u64)(2 * N - 1));
+    const u32 deg = m & (N - 1);
+    const u32 flip = (m >> log_n) & 1u;
+    const u32 v = glwe[(poly << log_n) + ((j - deg) & (N - 1))];
+    out[i] = (flip ^ (u32)(j < deg)) ? (0u - v) : v;
+  }
+}
+
+__global__ void sample_extract_kernel(u32 log_n, u32 k, const u32* __restrict__ glwe, size_t batch,
+                                      u32 sample_index, u32* __restrict__ lwe_out) {
+  // bootstrapping.rs:122-156: per mask polynomial p[idx], p[idx-1], ..., p[0], -p[N-1], ..., -p[idx+1]
+  const u32 N = 1u << log_n;
+  const size_t width = (size_t)k * N + 1;
+  const size_t total = batch * width;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = i / width;
+    const size_t x = i % width;
+    const u32* ct = glwe + b * (size_t)(k + 1) * N;
+    u32 v;
+    if (x == (size_t)k * N) {
+      v = ct[(size_t)k * N + sample_index];
+    } else {
+      const u32 p = (u32)(x >> log_n);
+      const u32 pos = (u32)(x & (N - 1));
+      v = (pos <= sample_index) ? ct[(size_t)p * N + (sample_index - pos)]
+                                : (0u - ct[(size_t)p * N + (N + sample_index - pos)]);
+    }
+    lwe_out[i] = v;
+  }
+}
+
+__global__ void lwe_gate_input_kernel(const u32* __restrict__ ct0, const u32* __restrict__ ct1,
+                                      size_t words, u32* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words;
+       i += (size_t)gridDim.x * blockDim.x)
+    out[i] = ct1[i] * 2u + ct0[i];
+}
+
+inline int grid_for(size_t work, int block) {
+  size_t g = (work + block - 1) / block;
+  if (g > 2048) g = 2048;  // 256 CUs x 8: grid-stride the rest
+  if (g == 0) g = 1;
+  return (int)g;
+}
+
+template <typename Kern>
+hipError_t allow_lds(Kern kern, size_t bytes) {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+template <int LOGN, int K>
+hipError_t launch_blind_rotate(hipStream_t s, const PbsParams& P, const u64* tw, const u32* lwe_in,
+                               size_t batch, const u32* tv, size_t tv_stride, const u64* bsk,
+                               u32* glwe_out, u32* lwe_extracted) {
+  using C = WaveCfg<LOGN, K>;
+  auto kern = blind_rotate_kernel<LOGN, K>;
+  hipError_t e = allow_lds(kern, C::kLds);
+  if (e != hipSuccess) return e;
+  const unsigned grid = (unsigned)((batch + C::kWaves - 1) / C::kWaves);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(C::kWaves * 64), C::kLds, s, P, tw, lwe_in, batch, tv,
+                     tv_stride, bsk, glwe_out, lwe_extracted);
+  return hipGetLastError();
+}
+
+template <int LOGN, int K>
+hipError_t launch_external_product(hipStream_t s, const PbsParams& P, const u64* tw, const u64* ggsw,
+                                   size_t ggsw_stride_words, const u32* glwe_in, u32* ct1_inout,
+                                   const u32* cmux_ct0, size_t batch, u32* glwe_out) {
+  using C = WaveCfg<LOGN, K>;
+  auto kern = external_product_kernel<LOGN, K>;
+  hipError_t e = allow_lds(kern, C::kLds);
+  if (e != hipSuccess) return e;
+  const unsigned grid = (unsigned)((batch + C::kWaves - 1) / C::kWaves);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(C::kWaves * 64), C::kLds, s, P, tw, ggsw,
+                     ggsw_stride_words, glwe_in, ct1_inout, cmux_ct0, batch, glwe_out);
+  return hipGetLastError();
+}
+
+template <int LOGN>
+hipError_t launch_bsk_prepare(hipStream_t s, const u64* tw, const u32* polys, size_t poly_count,
+                              u64* spectra) {
+  constexpr int N = 1 << LOGN;
+  constexpr int waves = 4;
+  const size_t lds = (size_t)N * 8 * (1 + waves);
+  auto kern = bsk_prepare_kernel<LOGN>;
+  hipError_t e = allow_lds(kern, lds);
+  if (e != hipSuccess) return e;
+  const unsigned grid = (unsigned)((poly_count + waves - 1) / waves);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(waves * 64), lds, s, tw, polys, poly_count, spectra,
+                     gl::inv((u64)N));
+  return hipGetLastError();
+}
+
+}  // namespace
+
+namespace launch {
+
+bool shape_supported(u32 log_n, u32 k) { return log_n >= 9 && log_n <= 11 && (k == 1 || k == 2); }
+
+int waves_per_block(u32 log_n, u32 /*k*/) { return log_n == 11 ? 2 : 4; }
+
+#if defined(TFHE_DEV_CFG2_ONLY)
+#define TFHE_DISPATCH_SHAPE(log_n, k, CALL)                                   \
+  do {                                                                        \
+    if ((k) == 1 && (log_n) == 10) {                                          \
+      constexpr int KK = 1;                                                   \
+      constexpr int LL = 10;                                                  \
+      return CALL;                                                            \
+    }                                                                         \
+    return hipErrorInvalidValue;                                              \
+  } while (0)
+#else
+#define TFHE_DISPATCH_SHAPE(log_n, k, CALL)                                   \
+  do {                                                                        \
+    if ((k) == 1) {                                                           \
+      constexpr int KK = 1;                                                   \
+      switch (log_n) {                                                        \
+        case 9: { constexpr int LL = 9; return CALL; }                        \
+        case 10: { constexpr int LL = 10; return CALL; }                      \
+        case 11: { constexpr int LL = 11; return CALL; }                      \
+        default: break;                                                       \
+      }                                                                       \
+    } else if ((k) == 2) {                                                    \
+      constexpr int KK = 2;                                                   \
+      switch (log_n) {                                                        \
+        case 9: { constexpr int LL = 9; return CALL; }                        \
+        case 10: { constexpr int LL = 10; return CALL; }                      \
+        case 11: { constexpr int LL = 11; return CALL; }                      \
+        default: break;                                                       \
+      }                                                                       \
+    }                                                                         \
+    return hipErrorInvalidValue;                                              \
+  } while (0)
+#endif
+
+hipError_t bsk_prepare(hipStream_t s, u32 log_n, const u64* tw, const u32* polys, size_t poly_count,
+                       u64* spectra) {
+  switch (log_n) {
+    case 9: return launch_bsk_prepare<9>(s, tw, polys, poly_count, spectra);
+    case 10: return launch_bsk_prepare<10>(s, tw, polys, poly_count, spectra);
+    case 11: return launch_bsk_prepare<11>(s, tw, polys, poly_count, spectra);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t blind_rotate(hipStream_t s, const PbsParams& P, const u64* tw, const u32* lwe_in,
+                        size_t batch, const u32* tv, size_t tv_stride, const u64* bsk,
+                        u32* glwe_out, u32* lwe_extracted) {
+  TFHE_DISPATCH_SHAPE(P.log_n, P.k,
+                      (launch_blind_rotate<LL, KK>(s, P, tw, lwe_in, batch, tv, tv_stride, bsk,
+                                                   glwe_out, lwe_extracted)));
+}
+
+hipError_t external_product(hipStream_t s, const PbsParams& P, const u64* tw, const u64* ggsw,
+                            size_t ggsw_stride_words, const u32* glwe_in, u32* ct1_inout,
+                            const u32* cmux_ct0, size_t batch, u32* glwe_out) {
+  TFHE_DISPATCH_SHAPE(P.log_n, P.k,
+                      (launch_external_product<LL, KK>(s, P, tw, ggsw, ggsw_stride_words, glwe_in,
+                                                       ct1_inout, cmux_ct0, batch, glwe_out)));
+}
+
+hipError_t key_switch(hipStream_t s, const KsParams& K, u32 big_n, u32 n, const u32* lwe_in,
+                      size_t batch, const u32* ksk, u32* lwe_out) {
+  const size_t lds = (size_t)kKsWords * K.levels * kKsSamples * sizeof(u32);
+  if (lds > 64 * 1024) return hipErrorInvalidValue;
+  dim3 grid((n + 1 + kKsCols - 1) / kKsCols, (unsigned)((batch + kKsSamples - 1) / kKsSamples));
+  hipLaunchKernelGGL(key_switch_kernel, grid, dim3(256), lds, s, K, big_n, n, lwe_in, batch, ksk,
+                     lwe_out);
+  return hipGetLastError();
+}
+
+static void decomposer_derived(u32 log_base, u32 levels, u32* ignored_bits, u32* first_shift) {
+  *ignored_bits = 32 - log_base * levels;
+  *first_shift = log_base * (32 / log_base - levels);
+}
+
+hipError_t decompose_words(hipStream_t s, u32 log_base, u32 levels, const u32* values, size_t count,
+                           u32* digits) {
+  u32 ig, fs;
+  decomposer_derived(log_base, levels, &ig, &fs);
+  hipLaunchKernelGGL(decompose_words_kernel, dim3(grid_for(count, 256)), dim3(256), 0, s, log_base,
+                     levels, ig, fs, values, count, digits);
+  return hipGetLastError();
+}
+
+hipError_t decompose_glwe(hipStream_t s, u32 log_base, u32 levels, u32 polys_per_ct, u32 n_coeff,
+                          const u32* glwe, size_t batch, u32* digits) {
+  u32 ig, fs;
+  decomposer_derived(log_base, levels, &ig, &fs);
+  const size_t total = batch * polys_per_ct * n_coeff;
+  hipLaunchKernelGGL(decompose_glwe_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, log_base,
+                     levels, ig, fs, polys_per_ct, n_coeff, glwe, total, digits);
+  return hipGetLastError();
+}
+
+hipError_t switch_modulus(hipStream_t s, const u32* values, size_t count, u32 log_from, u32 log_to,
+                          u32* out) {
+  hipLaunchKernelGGL(switch_modulus_kernel, dim3(grid_for(count, 256)), dim3(256), 0, s, values,
+                     count, log_from, log_to, out);
+  return hipGetLastError();
+}
+
+hipError_t glwe_mul_monomial(hipStream_t s, u32 log_n, u32 polys_per_ct, const u32* glwe,
+                             size_t batch, const i64* monomial_index, u32* out) {
+  const size_t total = (batch * polys_per_ct) << log_n;
+  hipLaunchKernelGGL(glwe_mul_monomial_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, log_n,
+                     polys_per_ct, glwe, total, monomial_index, out);
+  return hipGetLastError();
+}
+
+hipError_t sample_extract(hipStream_t s, u32 log_n, u32 k, const u32* glwe, size_t batch,
+                          u32 sample_index, u32* lwe_out) {
+  const size_t total = batch * (((size_t)k << log_n) + 1);
+  hipLaunchKernelGGL(sample_extract_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, log_n, k,
+                     glwe, batch, sample_index, lwe_out);
+  return hipGetLastError();
+}
+
+hipError_t lwe_gate_input(hipStream_t s, const u32* ct0, const u32* ct1, size_t words, u32* out) {
+  hipLaunchKernelGGL(lwe_gate_input_kernel, dim3(grid_for(words, 256)), dim3(256), 0, s, ct0, ct1,
+                     words, out);
+  return hipGetLastError();
+}
+
+}  // namespace launch
+}  // namespace tfhe

@@ -1,0 +1,52 @@
+// launch.h -- host-callable launchers of the gfx950 kernels (implemented in kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "pbs_wave.h"
+
+namespace tfhe {
+namespace launch {
+
+// true if a kernel set is instantiated for (log_n, k)
+bool shape_supported(u32 log_n, u32 k);
+// waves (= samples) per workgroup used by the per-wave kernels for this shape
+int waves_per_block(u32 log_n, u32 k);
+
+// twiddle table psi_rev[N] (u64) must already be on the device
+hipError_t bsk_prepare(hipStream_t s, u32 log_n, const u64* tw, const u32* polys, size_t poly_count,
+                       u64* spectra);
+
+// Blind rotation of `batch` samples.  Optional outputs: glwe_out [batch][k+1][N] and/or
+// lwe_extracted [batch][k*N+1] (sample extract at index 0 fused in).
+hipError_t blind_rotate(hipStream_t s, const PbsParams& P, const u64* tw, const u32* lwe_in,
+                        size_t batch, const u32* tv, size_t tv_stride, const u64* bsk,
+                        u32* glwe_out, u32* lwe_extracted);
+
+// out = external_product(ggsw[g], glwe[b]) (+ ct0 for the CMUX form).
+//   cmux_ct0 == nullptr : src = glwe_in
+//   cmux_ct0 != nullptr : src = ct1 - ct0 where ct1 = glwe_inout_ct1 (overwritten with the
+//                         difference, ggsw.rs:171), out = product + ct0
+hipError_t external_product(hipStream_t s, const PbsParams& P, const u64* tw, const u64* ggsw,
+                            size_t ggsw_stride_words, const u32* glwe_in, u32* ct1_inout,
+                            const u32* cmux_ct0, size_t batch, u32* glwe_out);
+
+// key_switch_lwe over a batch: lwe_in [batch][big_n+1], ksk [big_n*levels][n+1], out [batch][n+1]
+hipError_t key_switch(hipStream_t s, const KsParams& K, u32 big_n, u32 n, const u32* lwe_in,
+                      size_t batch, const u32* ksk, u32* lwe_out);
+
+// elementwise helpers
+hipError_t decompose_words(hipStream_t s, u32 log_base, u32 levels, const u32* values, size_t count,
+                           u32* digits /* [count][levels] */);
+hipError_t decompose_glwe(hipStream_t s, u32 log_base, u32 levels, u32 polys_per_ct, u32 n_coeff,
+                          const u32* glwe, size_t batch, u32* digits /* [batch][polys*levels][N] */);
+hipError_t switch_modulus(hipStream_t s, const u32* values, size_t count, u32 log_from, u32 log_to,
+                          u32* out);
+hipError_t glwe_mul_monomial(hipStream_t s, u32 log_n, u32 polys_per_ct, const u32* glwe,
+                             size_t batch, const i64* monomial_index, u32* out);
+hipError_t sample_extract(hipStream_t s, u32 log_n, u32 k, const u32* glwe, size_t batch,
+                          u32 sample_index, u32* lwe_out);
+// out = 2*ct1 + ct0 (boolean.rs:18)
+hipError_t lwe_gate_input(hipStream_t s, const u32* ct0, const u32* ct1, size_t words, u32* out);
+
+}  // namespace launch
+}  // namespace tfhe

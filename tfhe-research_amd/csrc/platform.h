@@ -1,0 +1,25 @@
+// platform.h -- one source for the GPU build (hipcc, gfx950) and for the host SIMT emulator that
+// the CPU tests use to run the very same per-lane code (tests/emu).  Not a portability layer for
+// other GPUs: the device side is written for 64-wide CDNA4 wavefronts only.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define TFHE_HD __host__ __device__ __forceinline__
+#define TFHE_D __device__ __forceinline__
+#else
+#define TFHE_HD inline
+#define TFHE_D inline
+#endif
+
+namespace tfhe {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef int32_t i32;
+typedef int64_t i64;
+
+constexpr int kWave = 64;  // CDNA wavefront width
+
+}  // namespace tfhe
