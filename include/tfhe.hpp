@@ -1,0 +1,269 @@
+// tfhe.hpp -- C++17 host-side mirror of the reference crate's bootstrapping-path interface, over
+// the C ABI of include/tfhe_hip.h.
+//
+// The reference (Janmajayamall/tfhe-research) is Rust; this image has no Rust toolchain, so the
+// host side above the C ABI is written in C++ with the reference's names, argument meaning and
+// error behaviour (its panics become C++ exceptions thrown HERE, never across the C ABI), so that
+// tests read like the reference's own.  A Rust shim with the same shape is shipped as source in
+// rust/ and described in INTEGRATION.md.  Citations are file:line under /root/reference/src.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <functional>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "tfhe_hip.h"
+
+namespace tfhe_amd {
+
+struct TfheError : std::runtime_error {
+  int status;
+  TfheError(int st, const std::string& what) : std::runtime_error(what), status(st) {}
+};
+
+// decomposer.rs:2-16
+struct DecomposerParams {
+  uint32_t log_base, levels, log_q;
+  DecomposerParams(uint32_t log_base_, uint32_t levels_, uint32_t log_q_ = 32)
+      : log_base(log_base_), levels(levels_), log_q(log_q_) {}
+};
+
+// lib.rs:23-74.  Fields are public here (the reference's are private with no constructor, which
+// makes every non-default parameter set unconstructible from outside the crate).
+struct TfheParams {
+  uint32_t glwe_dimension = 2;
+  uint32_t glwe_poly_degree = 9;  // log2 N (lib.rs:40)
+  uint32_t lwe_dimension = 722;
+  uint32_t padding_bits = 1;
+  uint32_t log_p = 2;
+  uint32_t log_q = 32;
+  DecomposerParams ks_decomposer{4, 5, 32};
+  DecomposerParams pbs_decomposer{4, 6, 32};
+
+  static TfheParams default_params() { return TfheParams{}; }  // lib.rs:101-123
+  static TfheParams default_test_params() {                    // lib.rs:77-99
+    TfheParams p;
+    p.lwe_dimension = 4;
+    return p;
+  }
+  size_t degree() const { return size_t(1) << glwe_poly_degree; }             // glwe.rs:124-127
+  size_t lwe_dimension_post_pbs() const { return degree() * glwe_dimension; }  // lib.rs:58-66
+  size_t ggsw_rows() const { return size_t(glwe_dimension + 1) * pbs_decomposer.levels; }
+
+  tfhe_params c() const {
+    tfhe_params p;
+    p.glwe_dimension = glwe_dimension;
+    p.glwe_poly_degree = glwe_poly_degree;
+    p.lwe_dimension = lwe_dimension;
+    p.padding_bits = padding_bits;
+    p.log_p = log_p;
+    p.log_q = log_q;
+    p.ks_decomposer = {ks_decomposer.log_base, ks_decomposer.levels, ks_decomposer.log_q};
+    p.pbs_decomposer = {pbs_decomposer.log_base, pbs_decomposer.levels, pbs_decomposer.log_q};
+    return p;
+  }
+};
+
+// lwe.rs:110-115: data = (a_0, ..., a_{n-1}, b)
+struct LweCiphertext {
+  std::vector<uint32_t> data;
+};
+// lwe.rs:9-15
+inline LweCiphertext operator+(const LweCiphertext& a, const LweCiphertext& b) {
+  if (a.data.size() != b.data.size()) throw TfheError(TFHE_ERR_INVALID_ARGUMENT, "LWE length mismatch");
+  LweCiphertext r{a.data};
+  for (size_t i = 0; i < r.data.size(); ++i) r.data[i] += b.data[i];
+  return r;
+}
+// lwe.rs:17-23
+inline LweCiphertext operator*(const LweCiphertext& a, uint32_t rhs) {
+  LweCiphertext r{a.data};
+  for (auto& v : r.data) v *= rhs;
+  return r;
+}
+
+// glwe.rs:185-188: row-major (k+1, N), body last
+struct GlweCiphertext {
+  std::vector<uint32_t> data;
+};
+// ggsw.rs:37-41: ((k+1)*l, k+1, N), row = poly_index*l + level
+struct GgswCiphertext {
+  std::vector<uint32_t> data;
+};
+// key_switching.rs:13-15: (k*N*l_ks, n+1)
+struct KeySwitchingKey {
+  std::vector<uint32_t> data;
+};
+// bootstrapping.rs:18-21
+struct BootstrappingKey {
+  std::vector<GgswCiphertext> lwe_sk_ggsw_enc;
+  KeySwitchingKey ksk;
+};
+// glwe.rs:16-18
+struct Monomial {
+  int64_t index;
+};
+
+// The GPU context: owns the device-side (NTT-domain) copy of one BootstrappingKey.
+class Engine {
+ public:
+  explicit Engine(const TfheParams& params, int device = 0) : params_(params) {
+    tfhe_params cp = params.c();
+    tfhe_context* raw = nullptr;
+    int st = tfhe_context_create(&cp, device, &raw);
+    if (st != TFHE_OK) throw TfheError(st, std::string("tfhe_context_create: ") + tfhe_status_string(st));
+    ctx_.reset(raw);
+  }
+
+  // Uploads the key in the reference's own layout (n separate GGSW arrays + the KSK array).
+  void load(const BootstrappingKey& bk) {
+    const size_t ggsw_words = params_.ggsw_rows() * (params_.glwe_dimension + 1) * params_.degree();
+    if (bk.lwe_sk_ggsw_enc.size() != params_.lwe_dimension)
+      throw TfheError(TFHE_ERR_INVALID_ARGUMENT, "bootstrapping key must hold n GGSW ciphertexts");
+    std::vector<uint32_t> flat;
+    flat.reserve(ggsw_words * bk.lwe_sk_ggsw_enc.size());
+    for (const auto& g : bk.lwe_sk_ggsw_enc) {
+      if (g.data.size() != ggsw_words) throw TfheError(TFHE_ERR_INVALID_ARGUMENT, "GGSW shape");
+      flat.insert(flat.end(), g.data.begin(), g.data.end());
+    }
+    const size_t ksk_words = params_.lwe_dimension_post_pbs() * params_.ks_decomposer.levels *
+                             (size_t(params_.lwe_dimension) + 1);
+    if (bk.ksk.data.size() != ksk_words) throw TfheError(TFHE_ERR_INVALID_ARGUMENT, "KSK shape");
+    check(tfhe_load_bootstrapping_key(ctx_.get(), flat.data(), bk.ksk.data.data()));
+  }
+
+  const TfheParams& params() const { return params_; }
+  tfhe_context* raw() const { return ctx_.get(); }
+  void check(int st) const {
+    if (st != TFHE_OK) throw TfheError(st, std::string(tfhe_status_string(st)) + ": " + tfhe_last_error(ctx_.get()));
+  }
+
+ private:
+  struct Deleter {
+    void operator()(tfhe_context* c) const { tfhe_context_destroy(c); }
+  };
+  TfheParams params_;
+  std::unique_ptr<tfhe_context, Deleter> ctx_;
+};
+
+// test_vector.rs:38-67
+inline std::vector<uint32_t> construct_test_from_lut(const TfheParams& p, const std::vector<uint32_t>& lut) {
+  std::vector<uint32_t> out(p.degree());
+  tfhe_params cp = p.c();
+  int st = tfhe_construct_test_from_lut(&cp, lut.data(), lut.size(), out.data());
+  if (st != TFHE_OK) throw TfheError(st, "construct_test_from_lut: lut must hold 2^log_p entries (test_vector.rs:41)");
+  return out;
+}
+// test_vector.rs:23-35
+inline std::vector<uint32_t> construct_identity_test_vector(const TfheParams& p) {
+  std::vector<uint32_t> lut(size_t(1) << p.log_p);
+  for (size_t i = 0; i < lut.size(); ++i) lut[i] = uint32_t(i);
+  return construct_test_from_lut(p, lut);
+}
+// test_vector.rs:5-20: f(lhs, rhs)
+inline std::vector<uint32_t> construct_test_vector_boolean(const TfheParams& p,
+                                                           const std::function<uint32_t(uint32_t, uint32_t)>& f) {
+  std::vector<uint32_t> lut(size_t(1) << p.log_p);
+  for (size_t i = 0; i < lut.size(); ++i) lut[i] = f(uint32_t(i >> 1) & 1u, uint32_t(i) & 1u);
+  return construct_test_from_lut(p, lut);
+}
+
+// bootstrap(): bootstrapping.rs:58-120, over a batch that shares one test vector.  The engine
+// replaces the reference's `&BootstrappingKey` argument (the key lives on the GPU after load()).
+inline std::vector<LweCiphertext> bootstrap_batch(Engine& e, const std::vector<LweCiphertext>& cts,
+                                                  const std::vector<uint32_t>& test_vector_poly) {
+  const size_t n1 = size_t(e.params().lwe_dimension) + 1;
+  std::vector<uint32_t> in(cts.size() * n1), out(cts.size() * n1);
+  for (size_t b = 0; b < cts.size(); ++b) {
+    if (cts[b].data.size() != n1) throw TfheError(TFHE_ERR_INVALID_ARGUMENT, "LWE length");
+    std::copy(cts[b].data.begin(), cts[b].data.end(), in.begin() + b * n1);
+  }
+  e.check(tfhe_bootstrap_batch(e.raw(), in.data(), cts.size(), test_vector_poly.data(), 1, out.data()));
+  std::vector<LweCiphertext> res(cts.size());
+  for (size_t b = 0; b < cts.size(); ++b) res[b].data.assign(out.begin() + b * n1, out.begin() + (b + 1) * n1);
+  return res;
+}
+inline LweCiphertext bootstrap(Engine& e, const LweCiphertext& lwe_ciphertext,
+                               const std::vector<uint32_t>& test_vector_poly) {
+  return bootstrap_batch(e, {lwe_ciphertext}, test_vector_poly)[0];
+}
+
+// key_switch_lwe(): key_switching.rs:63-103 (from the post-PBS dimension to n, with the loaded KSK)
+inline LweCiphertext key_switch_lwe(Engine& e, const LweCiphertext& ct) {
+  LweCiphertext out{std::vector<uint32_t>(size_t(e.params().lwe_dimension) + 1)};
+  if (ct.data.size() != e.params().lwe_dimension_post_pbs() + 1) throw TfheError(TFHE_ERR_INVALID_ARGUMENT, "LWE length");
+  e.check(tfhe_key_switch_batch(e.raw(), ct.data.data(), 1, out.data.data()));
+  return out;
+}
+
+// external_product(): ggsw.rs:132-161
+inline GlweCiphertext external_product(Engine& e, const GgswCiphertext& ggsw, const GlweCiphertext& glwe) {
+  GlweCiphertext out{std::vector<uint32_t>(glwe.data.size())};
+  e.check(tfhe_external_product_batch(e.raw(), ggsw.data.data(), 1, glwe.data.data(), 1, out.data.data()));
+  return out;
+}
+// cmux(): ggsw.rs:164-178 -- mutates glwe_ciphertext1 (ct1 -= ct0) like the reference
+inline GlweCiphertext cmux(Engine& e, const GgswCiphertext& ggsw, const GlweCiphertext& glwe_ciphertext0,
+                           GlweCiphertext& glwe_ciphertext1) {
+  GlweCiphertext out{std::vector<uint32_t>(glwe_ciphertext0.data.size())};
+  e.check(tfhe_cmux_batch(e.raw(), ggsw.data.data(), 1, glwe_ciphertext0.data.data(),
+                          glwe_ciphertext1.data.data(), 1, out.data.data()));
+  return out;
+}
+// &GlweCiphertext * &Monomial: glwe.rs:20-34
+inline GlweCiphertext operator_mul(Engine& e, const GlweCiphertext& glwe, const Monomial& m) {
+  GlweCiphertext out{std::vector<uint32_t>(glwe.data.size())};
+  e.check(tfhe_glwe_mul_monomial_batch(e.raw(), glwe.data.data(), 1, &m.index, out.data.data()));
+  return out;
+}
+// sample_extract(): bootstrapping.rs:122-156
+inline LweCiphertext sample_extract(Engine& e, const GlweCiphertext& glwe, size_t sample_index) {
+  LweCiphertext out{std::vector<uint32_t>(e.params().lwe_dimension_post_pbs() + 1)};
+  e.check(tfhe_sample_extract_batch(e.raw(), glwe.data.data(), 1, sample_index, out.data.data()));
+  return out;
+}
+
+// SignedDecomposer: decomposer.rs:18-96 (decompose runs on the device; round/recompose are trivial)
+class SignedDecomposer {
+ public:
+  SignedDecomposer(Engine& e, int which) : e_(e), which_(which) {}
+  std::vector<uint32_t> decompose(uint32_t value) const {  // decomposer.rs:42-80
+    const auto& d = which_ == TFHE_DECOMPOSER_PBS ? e_.params().pbs_decomposer : e_.params().ks_decomposer;
+    std::vector<uint32_t> out(d.levels);
+    e_.check(tfhe_decompose(e_.raw(), which_, &value, 1, out.data()));
+    return out;
+  }
+
+ private:
+  Engine& e_;
+  int which_;
+};
+
+// and()/or(): boolean.rs:9-53, plus the gates the reference leaves to the closure hook
+inline LweCiphertext gate(Engine& e, const uint32_t truth[4], const LweCiphertext& ct0, const LweCiphertext& ct1) {
+  LweCiphertext out{std::vector<uint32_t>(ct0.data.size())};
+  e.check(tfhe_gate_batch(e.raw(), truth, ct0.data.data(), ct1.data.data(), 1, out.data.data()));
+  return out;
+}
+inline LweCiphertext and_(Engine& e, const LweCiphertext& ct0, const LweCiphertext& ct1) {
+  const uint32_t t[4] = {0, 0, 0, 1};
+  return gate(e, t, ct0, ct1);
+}
+inline LweCiphertext or_(Engine& e, const LweCiphertext& ct0, const LweCiphertext& ct1) {
+  const uint32_t t[4] = {0, 1, 1, 1};
+  return gate(e, t, ct0, ct1);
+}
+inline LweCiphertext nand(Engine& e, const LweCiphertext& ct0, const LweCiphertext& ct1) {
+  const uint32_t t[4] = {1, 1, 1, 0};
+  return gate(e, t, ct0, ct1);
+}
+inline LweCiphertext xor_(Engine& e, const LweCiphertext& ct0, const LweCiphertext& ct1) {
+  const uint32_t t[4] = {0, 1, 1, 0};
+  return gate(e, t, ct0, ct1);
+}
+
+}  // namespace tfhe_amd

@@ -1,0 +1,144 @@
+//! Rust-side binding a maintainer of Janmajayamall/tfhe-research would add to call the MI355X
+//! engine from the crate, keeping the crate-internal signatures of the bootstrapping path.
+//! SOURCE ONLY (never compiled here: no Rust toolchain in the image).  The C ABI is
+//! `include/tfhe_hip.h`; everything below is plumbing between ndarray buffers and raw pointers.
+//!
+//! Reference signatures mirrored (file:line under src/):
+//!   bootstrap            bootstrapping.rs:58-65
+//!   key_switch_lwe       key_switching.rs:63-69
+//!   external_product     ggsw.rs:132-136        cmux   ggsw.rs:164-169
+//!   and / or             boolean.rs:9-14, 32-37
+//!   construct_test_from_lut  test_vector.rs:38
+use ndarray::{Array1, Array2, Array3};
+use std::os::raw::{c_char, c_int, c_void};
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct CDecomposerParams { pub log_base: u32, pub levels: u32, pub log_q: u32 }
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct CTfheParams {
+    pub glwe_dimension: u32, pub glwe_poly_degree: u32, pub lwe_dimension: u32,
+    pub padding_bits: u32, pub log_p: u32, pub log_q: u32,
+    pub ks_decomposer: CDecomposerParams, pub pbs_decomposer: CDecomposerParams,
+}
+
+#[repr(C)] pub struct TfheContext { _private: [u8; 0] }
+
+extern "C" {
+    fn tfhe_context_create(params: *const CTfheParams, device: c_int, out: *mut *mut TfheContext) -> c_int;
+    fn tfhe_context_destroy(ctx: *mut TfheContext);
+    fn tfhe_last_error(ctx: *const TfheContext) -> *const c_char;
+    fn tfhe_load_bootstrapping_key(ctx: *mut TfheContext, bsk: *const u32, ksk: *const u32) -> c_int;
+    fn tfhe_bootstrap_batch(ctx: *mut TfheContext, lwe_in: *const u32, batch: usize,
+                            test_vector_poly: *const u32, tv_count: usize, lwe_out: *mut u32) -> c_int;
+    fn tfhe_key_switch_batch(ctx: *mut TfheContext, lwe_in: *const u32, batch: usize, lwe_out: *mut u32) -> c_int;
+    fn tfhe_external_product_batch(ctx: *mut TfheContext, ggsw: *const u32, ggsw_count: usize,
+                                   glwe_in: *const u32, batch: usize, glwe_out: *mut u32) -> c_int;
+    fn tfhe_cmux_batch(ctx: *mut TfheContext, ggsw: *const u32, ggsw_count: usize, ct0: *const u32,
+                       ct1: *mut u32, batch: usize, glwe_out: *mut u32) -> c_int;
+    fn tfhe_gate_batch(ctx: *mut TfheContext, truth: *const u32, ct0: *const u32, ct1: *const u32,
+                       batch: usize, lwe_out: *mut u32) -> c_int;
+    fn tfhe_construct_test_from_lut(params: *const CTfheParams, lut: *const u32, lut_len: usize, out: *mut u32) -> c_int;
+    #[allow(dead_code)]
+    fn tfhe_context_set_stream(ctx: *mut TfheContext, hip_stream: *mut c_void) -> c_int;
+}
+
+/// The reference panics on failure (assert!/unwrap); so does this shim -- but only on the Rust
+/// side of the boundary: the C ABI itself returns status codes and never unwinds.
+fn check(ctx: *const TfheContext, status: c_int, what: &str) {
+    if status != 0 {
+        let msg = unsafe { std::ffi::CStr::from_ptr(tfhe_last_error(ctx)) }.to_string_lossy().into_owned();
+        panic!("{what}: status {status}: {msg}");
+    }
+}
+
+/// Owns the GPU context and the device copy of one `BootstrappingKey` (bootstrapping.rs:18-21).
+pub struct GpuBootstrappingKey { ctx: *mut TfheContext, params: CTfheParams }
+
+impl GpuBootstrappingKey {
+    /// `lwe_sk_ggsw_enc`: the n `GgswCiphertext.data` arrays ((k+1)l, k+1, N); `ksk`: `KeySwitchingKey.data`.
+    pub fn upload(params: CTfheParams, lwe_sk_ggsw_enc: &[Array3<u32>], ksk: &Array2<u32>) -> Self {
+        let mut ctx = std::ptr::null_mut();
+        let st = unsafe { tfhe_context_create(&params, 0, &mut ctx) };
+        assert!(st == 0, "tfhe_context_create: status {st}");
+        let mut flat = Vec::new();
+        for g in lwe_sk_ggsw_enc { flat.extend_from_slice(g.as_slice().unwrap()); }
+        check(ctx, unsafe { tfhe_load_bootstrapping_key(ctx, flat.as_ptr(), ksk.as_slice().unwrap().as_ptr()) }, "load key");
+        GpuBootstrappingKey { ctx, params }
+    }
+}
+
+impl Drop for GpuBootstrappingKey {
+    fn drop(&mut self) { unsafe { tfhe_context_destroy(self.ctx) } }
+}
+
+/// bootstrapping.rs:58-65.  `_lwe_secret_key` / `_glwe_secret_key` keep the positional slots of the
+/// reference signature; the reference never reads them (bootstrapping.rs:66-120) and neither do we.
+pub fn bootstrap<SK1, SK2>(bk: &GpuBootstrappingKey, lwe_ciphertext: &Array1<u32>, _lwe_secret_key: &SK1,
+                           _glwe_secret_key: &SK2, test_vector_poly: &Array1<u32>) -> Array1<u32> {
+    let mut out = Array1::<u32>::zeros(lwe_ciphertext.len());
+    check(bk.ctx, unsafe {
+        tfhe_bootstrap_batch(bk.ctx, lwe_ciphertext.as_slice().unwrap().as_ptr(), 1,
+                             test_vector_poly.as_slice().unwrap().as_ptr(), 1, out.as_slice_mut().unwrap().as_mut_ptr())
+    }, "bootstrap");
+    out
+}
+
+/// Batched form: `lwe_ciphertexts` is (batch, n+1) row-major.
+pub fn bootstrap_batch(bk: &GpuBootstrappingKey, lwe_ciphertexts: &Array2<u32>, test_vector_poly: &Array1<u32>) -> Array2<u32> {
+    let mut out = Array2::<u32>::zeros(lwe_ciphertexts.raw_dim());
+    check(bk.ctx, unsafe {
+        tfhe_bootstrap_batch(bk.ctx, lwe_ciphertexts.as_slice().unwrap().as_ptr(), lwe_ciphertexts.nrows(),
+                             test_vector_poly.as_slice().unwrap().as_ptr(), 1, out.as_slice_mut().unwrap().as_mut_ptr())
+    }, "bootstrap_batch");
+    out
+}
+
+/// key_switching.rs:63-69 (parameters and key come from the uploaded BootstrappingKey)
+pub fn key_switch_lwe(bk: &GpuBootstrappingKey, lwe_ciphertext: &Array1<u32>) -> Array1<u32> {
+    let mut out = Array1::<u32>::zeros(bk.params.lwe_dimension as usize + 1);
+    check(bk.ctx, unsafe { tfhe_key_switch_batch(bk.ctx, lwe_ciphertext.as_slice().unwrap().as_ptr(), 1, out.as_slice_mut().unwrap().as_mut_ptr()) }, "key_switch_lwe");
+    out
+}
+
+/// ggsw.rs:132-136
+pub fn external_product(bk: &GpuBootstrappingKey, ggsw_ciphertext: &Array3<u32>, glwe_ciphertext: &Array2<u32>) -> Array2<u32> {
+    let mut out = Array2::<u32>::zeros(glwe_ciphertext.raw_dim());
+    check(bk.ctx, unsafe {
+        tfhe_external_product_batch(bk.ctx, ggsw_ciphertext.as_slice().unwrap().as_ptr(), 1,
+                                    glwe_ciphertext.as_slice().unwrap().as_ptr(), 1, out.as_slice_mut().unwrap().as_mut_ptr())
+    }, "external_product");
+    out
+}
+
+/// ggsw.rs:164-169: `glwe_ciphertext1` is clobbered with ct1 - ct0, as in the reference.
+pub fn cmux(bk: &GpuBootstrappingKey, ggsw_ciphertext: &Array3<u32>, glwe_ciphertext0: &Array2<u32>, glwe_ciphertext1: &mut Array2<u32>) -> Array2<u32> {
+    let mut out = Array2::<u32>::zeros(glwe_ciphertext0.raw_dim());
+    check(bk.ctx, unsafe {
+        tfhe_cmux_batch(bk.ctx, ggsw_ciphertext.as_slice().unwrap().as_ptr(), 1, glwe_ciphertext0.as_slice().unwrap().as_ptr(),
+                        glwe_ciphertext1.as_slice_mut().unwrap().as_mut_ptr(), 1, out.as_slice_mut().unwrap().as_mut_ptr())
+    }, "cmux");
+    out
+}
+
+fn gate(bk: &GpuBootstrappingKey, truth: [u32; 4], ct0: &Array1<u32>, ct1: &Array1<u32>) -> Array1<u32> {
+    let mut out = Array1::<u32>::zeros(ct0.len());
+    check(bk.ctx, unsafe { tfhe_gate_batch(bk.ctx, truth.as_ptr(), ct0.as_slice().unwrap().as_ptr(), ct1.as_slice().unwrap().as_ptr(), 1, out.as_slice_mut().unwrap().as_mut_ptr()) }, "gate");
+    out
+}
+/// boolean.rs:9-14
+pub fn and(bk: &GpuBootstrappingKey, ct0: &Array1<u32>, ct1: &Array1<u32>) -> Array1<u32> { gate(bk, [0, 0, 0, 1], ct0, ct1) }
+/// boolean.rs:32-37
+pub fn or(bk: &GpuBootstrappingKey, ct0: &Array1<u32>, ct1: &Array1<u32>) -> Array1<u32> { gate(bk, [0, 1, 1, 1], ct0, ct1) }
+/// not in the reference; built through its closure hook construct_test_vector_boolean (test_vector.rs:5)
+pub fn nand(bk: &GpuBootstrappingKey, ct0: &Array1<u32>, ct1: &Array1<u32>) -> Array1<u32> { gate(bk, [1, 1, 1, 0], ct0, ct1) }
+
+/// test_vector.rs:38
+pub fn construct_test_from_lut(params: &CTfheParams, lut: &[u32]) -> Array1<u32> {
+    let mut out = Array1::<u32>::zeros(1usize << params.glwe_poly_degree);
+    let st = unsafe { tfhe_construct_test_from_lut(params, lut.as_ptr(), lut.len(), out.as_slice_mut().unwrap().as_mut_ptr()) };
+    assert!(st == 0, "lut must hold 2^log_p entries (test_vector.rs:41)");
+    out
+}

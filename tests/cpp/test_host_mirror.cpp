@@ -1,0 +1,152 @@
+// GPU test of the C++ host-side mirror (include/tfhe.hpp).  Written to read like the reference's
+// own tests (bootstrapping.rs:194-230, boolean.rs:67-101, key_switching.rs:118-159,
+// ggsw.rs:203-280), with the CPU oracle supplying keys/encryption (test infrastructure) and the
+// bit-exact expected values.
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "tfhe.hpp"
+#include "tfhe_oracle.h"
+
+using namespace tfhe_amd;
+
+static int failures = 0;
+#define EXPECT(cond, msg)                                         \
+  do {                                                            \
+    if (!(cond)) {                                                \
+      ++failures;                                                 \
+      std::fprintf(stderr, "FAIL %s:%d %s\n", __FILE__, __LINE__, msg); \
+    }                                                             \
+  } while (0)
+
+static orc_params to_orc(const TfheParams& p) {
+  orc_params o;
+  orc_params_default(&o, 1);
+  o.glwe_dimension = p.glwe_dimension;
+  o.glwe_poly_degree = p.glwe_poly_degree;
+  o.lwe_dimension = p.lwe_dimension;
+  o.padding_bits = p.padding_bits;
+  o.log_p = p.log_p;
+  o.ks_decomposer = {p.ks_decomposer.log_base, p.ks_decomposer.levels, 32};
+  o.pbs_decomposer = {p.pbs_decomposer.log_base, p.pbs_decomposer.levels, 32};
+  return o;
+}
+
+int main() {
+  orc_set_poly_mul_mode(1);
+  TfheParams tfhe_params = TfheParams::default_test_params();
+  orc_params op = to_orc(tfhe_params);
+  const size_t n = tfhe_params.lwe_dimension, N = tfhe_params.degree(), k = tfhe_params.glwe_dimension;
+  orc_rng rng;
+  orc_rng_seed(&rng, 77);
+
+  // keys (bootstrapping_key_gen, bootstrapping.rs:23-56) in the reference's in-memory shape
+  std::vector<uint32_t> lwe_sk(n), glwe_sk(k * N), bsk(orc_bsk_words(&op)), ksk(orc_ksk_words(&op));
+  orc_lwe_secret_key_random(&op, &rng, lwe_sk.data());
+  orc_glwe_secret_key_random(&op, &rng, glwe_sk.data());
+  orc_bootstrapping_key_gen(&op, lwe_sk.data(), glwe_sk.data(), &rng, bsk.data(), ksk.data());
+  BootstrappingKey bootstrapping_key;
+  const size_t ggsw_words = orc_ggsw_words(&op);
+  for (size_t i = 0; i < n; ++i)
+    bootstrapping_key.lwe_sk_ggsw_enc.push_back(GgswCiphertext{
+        std::vector<uint32_t>(bsk.begin() + i * ggsw_words, bsk.begin() + (i + 1) * ggsw_words)});
+  bootstrapping_key.ksk.data = ksk;
+
+  Engine engine(tfhe_params);
+  engine.load(bootstrapping_key);
+
+  auto encrypt = [&](uint32_t m) {
+    uint32_t pt;
+    orc_lwe_encode(&op, m, &pt);
+    LweCiphertext ct{std::vector<uint32_t>(n + 1)};
+    orc_encrypt_lwe_plaintext(n, op.lwe_std_dev, lwe_sk.data(), pt, &rng, ct.data.data());
+    return ct;
+  };
+  auto decrypt = [&](const LweCiphertext& ct) {
+    uint32_t raw = orc_decrypt_lwe(n, lwe_sk.data(), ct.data.data());
+    return orc_lwe_decode(&op, raw + (1u << (32 - op.log_p - op.padding_bits - 1))) & 3u;
+  };
+
+  // bootstrapping_works
+  {
+    auto test_vector_poly = construct_identity_test_vector(tfhe_params);
+    for (uint32_t m = 0; m < 4; ++m) {
+      LweCiphertext lwe_ciphertext = encrypt(m);
+      LweCiphertext bootstrapped = bootstrap(engine, lwe_ciphertext, test_vector_poly);
+      EXPECT(decrypt(bootstrapped) == m, "bootstrapping_works");
+      std::vector<uint32_t> want(n + 1);
+      orc_bootstrap(&op, lwe_ciphertext.data.data(), bsk.data(), ksk.data(), test_vector_poly.data(), want.data(), nullptr);
+      EXPECT(bootstrapped.data == want, "bootstrap bit-exact vs oracle");
+    }
+  }
+  // boolean_gates_work (and, or, plus nand/xor through the closure hook)
+  for (uint32_t i = 0; i < 4; ++i) {
+    uint32_t lhs = (i >> 1) & 1, rhs = i & 1;
+    LweCiphertext ct1 = encrypt(lhs), ct0 = encrypt(rhs);
+    EXPECT(decrypt(and_(engine, ct0, ct1)) == (lhs & rhs), "and");
+    EXPECT(decrypt(or_(engine, ct0, ct1)) == (lhs | rhs), "or");
+    EXPECT(decrypt(nand(engine, ct0, ct1)) == (1 - (lhs & rhs)), "nand");
+    EXPECT(decrypt(xor_(engine, ct0, ct1)) == (lhs ^ rhs), "xor");
+    // the gate input is 2*ct1 + ct0 (boolean.rs:18)
+    LweCiphertext ct_in = ct1 * 2u + ct0;
+    auto tv = construct_test_vector_boolean(tfhe_params, [](uint32_t l, uint32_t r) { return l & r; });
+    EXPECT(bootstrap(engine, ct_in, tv).data == and_(engine, ct0, ct1).data, "and == bootstrap(2*ct1+ct0)");
+  }
+  // external_product / cmux / key_switch_lwe / sample_extract / decompose: bit-exact vs oracle
+  {
+    std::vector<uint32_t> ggsw(ggsw_words), c0((k + 1) * N), c1((k + 1) * N), want((k + 1) * N);
+    orc_fill_uniform_u32(&rng, ggsw.data(), ggsw.size());
+    orc_fill_uniform_u32(&rng, c0.data(), c0.size());
+    orc_fill_uniform_u32(&rng, c1.data(), c1.size());
+    GgswCiphertext g{ggsw};
+    GlweCiphertext ct0{c0}, ct1{c1};
+    orc_external_product(&op, ggsw.data(), c0.data(), want.data());
+    EXPECT(external_product(engine, g, ct0).data == want, "external_product");
+    std::vector<uint32_t> c1_ref = c1;
+    orc_cmux(&op, ggsw.data(), c0.data(), c1_ref.data(), want.data());
+    GlweCiphertext res = cmux(engine, g, ct0, ct1);
+    EXPECT(res.data == want, "cmux result");
+    EXPECT(ct1.data == c1_ref, "cmux clobbers ct1 with ct1 - ct0 (ggsw.rs:171)");
+
+    LweCiphertext extracted = sample_extract(engine, res, 0);
+    std::vector<uint32_t> want_lwe(k * N + 1);
+    orc_sample_extract(&op, res.data.data(), 0, want_lwe.data());
+    EXPECT(extracted.data == want_lwe, "sample_extract");
+    LweCiphertext switched = key_switch_lwe(engine, extracted);
+    std::vector<uint32_t> want_ks(n + 1);
+    orc_key_switch_lwe(extracted.data.data(), k * N, n, &op.ks_decomposer, ksk.data(), want_ks.data());
+    EXPECT(switched.data == want_ks, "key_switch_lwe");
+
+    GlweCiphertext rot = operator_mul(engine, ct0, Monomial{-5});
+    orc_glwe_mul_monomial(c0.data(), k + 1, N, -5, want.data());
+    EXPECT(rot.data == want, "glwe * monomial");
+
+    SignedDecomposer dec(engine, TFHE_DECOMPOSER_PBS);
+    uint32_t legs[32];
+    orc_decompose(&op.pbs_decomposer, 0xABCDEF12u, legs);
+    auto got = dec.decompose(0xABCDEF12u);
+    EXPECT(got.size() == op.pbs_decomposer.levels && std::memcmp(got.data(), legs, got.size() * 4) == 0, "decompose");
+  }
+  // error behaviour: the reference panics, the mirror throws
+  {
+    bool threw = false;
+    try {
+      construct_test_from_lut(tfhe_params, {0, 1, 2});  // assert!(lut.len() == 2^log_p)
+    } catch (const TfheError&) { threw = true; }
+    EXPECT(threw, "lut length assert");
+    threw = false;
+    try {
+      TfheParams bad = tfhe_params;
+      bad.pbs_decomposer = DecomposerParams(7, 5);  // levels > floor(32/7): endless loop in the reference
+      Engine e2(bad);
+    } catch (const TfheError&) { threw = true; }
+    EXPECT(threw, "invalid decomposer rejected");
+  }
+  if (failures) {
+    std::fprintf(stderr, "%d failure(s)\n", failures);
+    return 1;
+  }
+  std::printf("host mirror OK\n");
+  return 0;
+}
