@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="auto", choices=["auto", "goldilocks", "fp64"])
     args = ap.parse_args()
 
     import torch
@@ -119,7 +120,9 @@ def main():
     tv = torch.from_numpy(pkg.construct_identity_test_vector(params).astype(np.int32)).to(dev)
     out = torch.empty_like(lwe)
 
-    ctx = pkg.Context(params, device=local_rank)
+    backend = {"auto": pkg.BACKEND_AUTO, "goldilocks": pkg.BACKEND_GOLDILOCKS, "fp64": pkg.BACKEND_FP64}[args.backend]
+    ctx = pkg.Context(params, device=local_rank, backend=backend)
+    backend_name = ctx.backend
     ctx.use_torch_stream()
     ctx.load_bootstrapping_key(bsk, ksk)
     del bsk
@@ -167,7 +170,8 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "u64 (exact Goldilocks NTT of wrapping-u32 data)",
+        "dtype": ("f64 (exact NTT mod a 42-bit prime; data is wrapping u32)" if backend_name.startswith("fp64")
+                  else "u64 (exact Goldilocks NTT; data is wrapping u32)"),
         "data": "synthetic",
         "config": {
             "workload": f"{args.workload}: batch {batch}/GPU, N={1 << logn}, k={k}, n={n}, l={pbs[1]}, log2B={pbs[0]}, "
@@ -176,7 +180,7 @@ def main():
             "parallelism": f"dp{world} (independent LWE shards, keys replicated)",
         },
         "roofline": {
-            "kernel": f"blind_rotate_kernel<{logn},{k}>",
+            "kernel": f"blind_rotate_kernel<{backend_name},{logn},{k}>",
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,

@@ -72,9 +72,24 @@ void tfhe_params_default(tfhe_params *params, int cfg_test);
 /* 0 if the reference could run this parameter set (no underflow / endless loop / shift >= 32) */
 int tfhe_params_validate(const tfhe_params *params);
 
+/* Exact-NTT backends.  Both give identical bits; they differ in speed and in the parameter sets
+ * they can lift exactly (checked at context creation, TFHE_ERR_EXACTNESS otherwise):
+ *   FP64       42-bit prime, fp64 arithmetic, key split into 16-bit halves; needs
+ *              (k+1)*l * N * B * 2^15 < 2^40.9
+ *   GOLDILOCKS p = 2^64 - 2^32 + 1, u64 arithmetic; needs (k+1)*l * N * B * 2^32 < 2^62
+ *   AUTO       FP64 when its bound holds, else GOLDILOCKS (env TFHE_HIP_BACKEND=fp64|goldilocks
+ *              overrides AUTO). */
+#define TFHE_BACKEND_AUTO 0
+#define TFHE_BACKEND_GOLDILOCKS 1
+#define TFHE_BACKEND_FP64 2
+
 /* Creates a context bound to HIP device `device`.  Fails with TFHE_ERR_NO_DEVICE when no GPU is
  * present: there is deliberately no CPU path behind this ABI. */
 int tfhe_context_create(const tfhe_params *params, int device, tfhe_context **out);
+int tfhe_context_create_with_backend(const tfhe_params *params, int device, int backend,
+                                     tfhe_context **out);
+/* "fp64-p42" or "goldilocks" */
+const char *tfhe_context_backend(const tfhe_context *ctx);
 void tfhe_context_destroy(tfhe_context *ctx);
 /* Use an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream. */
 int tfhe_context_set_stream(tfhe_context *ctx, void *hip_stream);
@@ -126,10 +141,12 @@ int tfhe_key_switch_batch_device(tfhe_context *ctx, const uint32_t *lwe_in, size
  * (one GGSW for the whole batch, the blind-rotation shape) or batch; glwe [batch][k+1][N]. */
 int tfhe_external_product_batch(tfhe_context *ctx, const uint32_t *ggsw, size_t ggsw_count,
                                 const uint32_t *glwe_in, size_t batch, uint32_t *glwe_out);
-/* Device-pointer form used by the benchmark: `ggsw_prepared` comes from tfhe_prepare_ggsw_device. */
+/* Device-pointer form used by the benchmark: `ggsw_prepared` (NTT domain, 8-byte words,
+ * tfhe_prepared_ggsw_words() of them per GGSW) comes from tfhe_prepare_ggsw_device. */
+int tfhe_prepared_ggsw_words(const tfhe_context *ctx, size_t *words);
 int tfhe_prepare_ggsw_device(tfhe_context *ctx, const uint32_t *ggsw, size_t ggsw_count,
-                             uint64_t *ggsw_prepared);
-int tfhe_external_product_prepared_device(tfhe_context *ctx, const uint64_t *ggsw_prepared,
+                             void *ggsw_prepared);
+int tfhe_external_product_prepared_device(tfhe_context *ctx, const void *ggsw_prepared,
                                           size_t ggsw_count, const uint32_t *glwe_in, size_t batch,
                                           uint32_t *glwe_out);
 /* cmux(): ggsw.rs:164-178.  Like the reference, ct1 is CLOBBERED with ct1 - ct0. */

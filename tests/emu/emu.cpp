@@ -19,89 +19,111 @@ using namespace tfhe;
 
 namespace {
 
-struct HostWave {
-  int lane_;
-  pthread_barrier_t* bar_;
-  u64* scratch_;
-  u32* acc_;
-  const u64* tw_;
-  int lane() const { return lane_; }
-  void sync() const { pthread_barrier_wait(bar_); }
-  u64* scratch() const { return scratch_; }
-  u32* acc() const { return acc_; }
-  const u64* twiddles() const { return tw_; }
-  u32 uniform(u32 v) const { return v; }
+template <class Elem>
+struct HostTeam {
+  int n;
+  std::vector<Elem> scratch, tw;
+  std::vector<u32> acc;
+  pthread_barrier_t team_bar;
+  std::vector<pthread_barrier_t> wave_bars;
 };
 
-// run body(ctx) on 64 lanes
-void run_wave(int logn, int k, const std::function<void(const HostWave&)>& body) {
-  const int n = 1 << logn;
-  std::vector<u64> scratch(n), tw(n);
-  std::vector<u32> acc((size_t)(k + 1) * n);
-  ntt_fill_twiddles(logn, tw.data());
-  pthread_barrier_t bar;
-  pthread_barrier_init(&bar, nullptr, kWave);
+template <class Elem>
+struct HostWave {
+  int lane_, wave_;
+  HostTeam<Elem>* t_;
+  int lane() const { return lane_; }
+  int wave() const { return wave_; }
+  void sync() const { pthread_barrier_wait(&t_->wave_bars[wave_]); }
+  void team_sync() const { pthread_barrier_wait(&t_->team_bar); }
+  Elem* scratch() const { return t_->scratch.data() + (size_t)wave_ * t_->n; }
+  const Elem* scratch_of(int s) const { return t_->scratch.data() + (size_t)s * t_->n; }
+  u32* acc() const { return t_->acc.data() + (size_t)wave_ * t_->n; }
+  const Elem* twiddles() const { return t_->tw.data(); }
+  u32 uniform(u32 v) const { return v; }
+  void keep(u32) const {}
+  void compiler_fence() const {}
+};
+
+// run body(ctx) on a team of `waves` wavefronts x 64 lanes (one OS thread per lane)
+template <class F>
+void run_team(int logn, int waves, const std::function<void(const HostWave<typename F::elem>&)>& body) {
+  typedef typename F::elem elem;
+  HostTeam<elem> team;
+  team.n = 1 << logn;
+  team.scratch.resize((size_t)waves * team.n);
+  team.acc.resize((size_t)waves * team.n);
+  team.tw.resize(team.n);
+  F::fill_twiddles(logn, team.tw.data());
+  pthread_barrier_init(&team.team_bar, nullptr, waves * kWave);
+  team.wave_bars.resize(waves);
+  for (auto& b : team.wave_bars) pthread_barrier_init(&b, nullptr, kWave);
   std::vector<std::thread> th;
-  for (int l = 0; l < kWave; ++l)
-    th.emplace_back([&, l] {
-      HostWave w{l, &bar, scratch.data(), acc.data(), tw.data()};
-      body(w);
-    });
+  for (int w = 0; w < waves; ++w)
+    for (int l = 0; l < kWave; ++l)
+      th.emplace_back([&, w, l] {
+        HostWave<elem> ctx{l, w, &team};
+        body(ctx);
+      });
   for (auto& t : th) t.join();
-  pthread_barrier_destroy(&bar);
 }
 
-template <int LOGN>
-void poly_ntt(const u64* in, u64* out, int inverse) {
+template <class F, int LOGN>
+void poly_ntt(const typename F::elem* in, typename F::elem* out, int inverse) {
+  typedef typename F::elem elem;
   constexpr int E = NttShape<LOGN>::kE;
-  run_wave(LOGN, 0, [&](const HostWave& w) {
-    u64 x[E];
+  run_team<F>(LOGN, 1, [&](const HostWave<elem>& w) {
+    elem x[E];
     if (!inverse) {
       for (int r = 0; r < E; ++r) x[r] = in[r * 64 + w.lane()];
-      ntt_forward<LOGN>(w, x);
+      ntt_forward<F, LOGN>(w, x);
       for (int r = 0; r < E; ++r) out[w.lane() * E + r] = x[r];
     } else {
       for (int r = 0; r < E; ++r) x[r] = in[w.lane() * E + r];
-      ntt_inverse<LOGN>(w, x);
+      ntt_inverse<F, LOGN>(w, x);
       for (int r = 0; r < E; ++r) out[r * 64 + w.lane()] = x[r];
     }
   });
 }
 
-template <int LOGN>
-void bsk_prepare(size_t polys, const u32* src, u64* dst) {
+template <class F, int LOGN>
+void bsk_prepare(size_t polys, const u32* src, typename F::elem* dst) {
+  typedef typename F::elem elem;
   constexpr int N = 1 << LOGN;
-  const u64 n_inv = gl::inv((u64)N);
-  run_wave(LOGN, 0, [&](const HostWave& w) {
-    for (size_t i = 0; i < polys; ++i) bsk_prepare_wave<LOGN>(w, src + i * N, dst + i * N, n_inv);
+  const elem n_inv = F::n_inv(LOGN);
+  run_team<F>(LOGN, 1, [&](const HostWave<elem>& w) {
+    for (size_t i = 0; i < polys; ++i)
+      bsk_prepare_wave<F, LOGN>(w, src + i * N, dst + i * N * F::kParts, n_inv);
   });
 }
 
-template <int LOGN, int K>
+template <class F, int LOGN, int K>
 void blind_rotate(const PbsParams& P, size_t batch, const u32* lwe, const u32* tv, size_t tv_stride,
-                  const u64* bsk, u32* out_glwe, u32* out_lwe) {
+                  const typename F::elem* bsk, u32* out_glwe, u32* out_lwe) {
+  typedef typename F::elem elem;
   constexpr int N = 1 << LOGN;
   constexpr int E = NttShape<LOGN>::kE;
-  run_wave(LOGN, K, [&](const HostWave& w) {
+  run_team<F>(LOGN, K + 1, [&](const HostWave<elem>& w) {
     for (size_t b = 0; b < batch; ++b) {
-      blind_rotate_wave<LOGN, K>(w, P, lwe + b * (P.n + 1), tv + b * tv_stride, bsk);
+      blind_rotate_team<F, LOGN, K>(w, P, lwe + b * (P.n + 1), tv + b * tv_stride, bsk);
       if (out_glwe)
-        for (int p = 0; p <= K; ++p)
-          for (int r = 0; r < E; ++r)
-            out_glwe[(b * (K + 1) + p) * N + r * 64 + w.lane()] = w.acc()[p * N + r * 64 + w.lane()];
-      if (out_lwe) sample_extract_wave<LOGN, K>(w, out_lwe + b * ((size_t)K * N + 1));
-      w.sync();
+        for (int r = 0; r < E; ++r)
+          out_glwe[(b * (K + 1) + w.wave()) * N + r * 64 + w.lane()] = w.acc()[r * 64 + w.lane()];
+      if (out_lwe) sample_extract_team<LOGN, K>(w, out_lwe + b * ((size_t)K * N + 1));
+      w.team_sync();
     }
   });
 }
 
-template <int LOGN, int K>
-void ext_product(const PbsParams& P, const u64* ggsw, const u32* glwe, u32* out) {
+template <class F, int LOGN, int K>
+void ext_product(const PbsParams& P, const typename F::elem* ggsw, const u32* glwe, u32* out) {
+  typedef typename F::elem elem;
   constexpr int N = 1 << LOGN;
-  run_wave(LOGN, K, [&](const HostWave& w) {
-    auto src = [&](int p, int j) -> u32 { return glwe[p * N + j]; };
-    auto dst = [&](int p, int j, u32 v) { out[p * N + j] = v; };
-    external_product_wave<LOGN, K>(w, P, ggsw, src, dst);
+  run_team<F>(LOGN, K + 1, [&](const HostWave<elem>& w) {
+    const int p = w.wave();
+    auto src = [&](int j) -> u32 { return glwe[p * N + j]; };
+    auto dst = [&](int j, u32 v) { out[p * N + j] = v; };
+    external_product_team<F, LOGN, K>(w, P, ggsw, src, dst);
   });
 }
 
@@ -128,15 +150,23 @@ PbsParams make_params(u32 n, u32 k, u32 log_n, u32 log_p, u32 padding, u32 log_b
     default: return 1;                       \
   }
 
+// field: 1 = Goldilocks (u64 elements), 2 = fp64 prime (double elements); buffers are 8-byte words
+#define DISPATCH_FIELD(field, CALL)                    \
+  if ((field) == 1) { typedef GlField FF; CALL; }      \
+  else if ((field) == 2) { typedef FpField FF; CALL; } \
+  else return 3;
+
 extern "C" {
 
-int emu_poly_ntt(int logn, const u64* in, u64* out, int inverse) {
-  DISPATCH_LOGN(logn, poly_ntt<L>(in, out, inverse));
+int emu_field_parts(int field) { return field == 2 ? FpField::kParts : GlField::kParts; }
+
+int emu_poly_ntt(int field, int logn, const void* in, void* out, int inverse) {
+  DISPATCH_FIELD(field, DISPATCH_LOGN(logn, (poly_ntt<FF, L>((const FF::elem*)in, (FF::elem*)out, inverse))));
   return 0;
 }
 
-int emu_twiddles(int logn, u64* out) {
-  ntt_fill_twiddles(logn, out);
+int emu_twiddles(int field, int logn, void* out) {
+  DISPATCH_FIELD(field, FF::fill_twiddles(logn, (FF::elem*)out));
   return 0;
 }
 
@@ -148,27 +178,38 @@ u32 emu_gl_lift(u64 v) { return gl::lift_mod_2_32(v); }
 void emu_gl_mul_many(const u64* a, const u64* b, u64* out, size_t len) {
   for (size_t i = 0; i < len; ++i) out[i] = gl::mul(a[i], b[i]);
 }
+double emu_fp_p() { return FpField::P; }
+void emu_fp_mul_many(const double* a, const double* w, double* out, size_t len) {
+  for (size_t i = 0; i < len; ++i) out[i] = FpField::mul(a[i], w[i]);
+}
+void emu_fp_reduce_many(const double* a, double* out, size_t len) {
+  for (size_t i = 0; i < len; ++i) out[i] = FpField::reduce(a[i]);
+}
+void emu_fp_to_u32_many(const double* a, u32* out, size_t len) {
+  for (size_t i = 0; i < len; ++i) out[i] = FpField::to_u32(a[i]);
+}
+double emu_fp_from_key_word(u32 w, int part) { return FpField::from_key_word(w, part); }
 
-int emu_bsk_prepare(int logn, size_t polys, const u32* src, u64* dst) {
-  DISPATCH_LOGN(logn, bsk_prepare<L>(polys, src, dst));
+int emu_bsk_prepare(int field, int logn, size_t polys, const u32* src, void* dst) {
+  DISPATCH_FIELD(field, DISPATCH_LOGN(logn, (bsk_prepare<FF, L>(polys, src, (FF::elem*)dst))));
   return 0;
 }
 
-int emu_blind_rotate(u32 n, u32 k, u32 logn, u32 log_p, u32 padding, u32 log_base, u32 levels,
-                     size_t batch, const u32* lwe, const u32* tv, size_t tv_stride, const u64* bsk,
-                     u32* out_glwe, u32* out_lwe) {
+int emu_blind_rotate(int field, u32 n, u32 k, u32 logn, u32 log_p, u32 padding, u32 log_base,
+                     u32 levels, size_t batch, const u32* lwe, const u32* tv, size_t tv_stride,
+                     const void* bsk, u32* out_glwe, u32* out_lwe) {
   PbsParams P = make_params(n, k, logn, log_p, padding, log_base, levels);
-  if (k == 1) { DISPATCH_LOGN(logn, (blind_rotate<L, 1>(P, batch, lwe, tv, tv_stride, bsk, out_glwe, out_lwe))); }
-  else if (k == 2) { DISPATCH_LOGN(logn, (blind_rotate<L, 2>(P, batch, lwe, tv, tv_stride, bsk, out_glwe, out_lwe))); }
+  if (k == 1) { DISPATCH_FIELD(field, DISPATCH_LOGN(logn, (blind_rotate<FF, L, 1>(P, batch, lwe, tv, tv_stride, (const FF::elem*)bsk, out_glwe, out_lwe)))); }
+  else if (k == 2) { DISPATCH_FIELD(field, DISPATCH_LOGN(logn, (blind_rotate<FF, L, 2>(P, batch, lwe, tv, tv_stride, (const FF::elem*)bsk, out_glwe, out_lwe)))); }
   else return 2;
   return 0;
 }
 
-int emu_external_product(u32 k, u32 logn, u32 log_base, u32 levels, const u64* ggsw,
+int emu_external_product(int field, u32 k, u32 logn, u32 log_base, u32 levels, const void* ggsw,
                          const u32* glwe, u32* out) {
   PbsParams P = make_params(0, k, logn, 2, 1, log_base, levels);
-  if (k == 1) { DISPATCH_LOGN(logn, (ext_product<L, 1>(P, ggsw, glwe, out))); }
-  else if (k == 2) { DISPATCH_LOGN(logn, (ext_product<L, 2>(P, ggsw, glwe, out))); }
+  if (k == 1) { DISPATCH_FIELD(field, DISPATCH_LOGN(logn, (ext_product<FF, L, 1>(P, (const FF::elem*)ggsw, glwe, out)))); }
+  else if (k == 2) { DISPATCH_FIELD(field, DISPATCH_LOGN(logn, (ext_product<FF, L, 2>(P, (const FF::elem*)ggsw, glwe, out)))); }
   else return 2;
   return 0;
 }

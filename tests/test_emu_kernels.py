@@ -25,13 +25,23 @@ def emu():
     so = os.path.join(EMU_DIR, "libtfhe_emu.so")
     srcs = [os.path.join(EMU_DIR, "emu.cpp")] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I", CSRC,
+        subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread", "-I", CSRC,
                         "-o", so, os.path.join(EMU_DIR, "emu.cpp")], check=True)
     lib = C.CDLL(so)
     for f in ("emu_gl_mul", "emu_gl_add", "emu_gl_sub", "emu_gl_from_i32"):
         getattr(lib, f).restype = C.c_uint64
     lib.emu_gl_lift.restype = C.c_uint32
+    lib.emu_fp_p.restype = C.c_double
+    lib.emu_fp_from_key_word.restype = C.c_double
     return lib
+
+
+GL, FP = 1, 2
+FIELDS = [GL, FP]
+
+
+def pd(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
 def p64(a):
@@ -75,23 +85,85 @@ def test_wave_ntt_matches_model(emu, logn):
     n = 1 << logn
     fwd, inv = ntt_model.tables(logn)
     tw = np.zeros(n, dtype=np.uint64)
-    emu.emu_twiddles(logn, p64(tw))
+    emu.emu_twiddles(GL, logn, p64(tw))
     assert tw.tolist() == fwd
     rng = np.random.default_rng(logn)
     a = np.array([int(x) % P for x in rng.integers(0, 1 << 64, size=n, dtype=np.uint64)], dtype=np.uint64)
     out = np.zeros_like(a)
-    assert emu.emu_poly_ntt(logn, p64(a), p64(out), 0) == 0
+    assert emu.emu_poly_ntt(GL, logn, p64(a), p64(out), 0) == 0
     ref = ntt_model.ntt_ref(a.tolist(), logn, fwd)
     assert out.tolist() == ref
     back = np.zeros_like(a)
-    assert emu.emu_poly_ntt(logn, p64(out), p64(back), 1) == 0
+    assert emu.emu_poly_ntt(GL, logn, p64(out), p64(back), 1) == 0
     assert back.tolist() == [x * n % P for x in a.tolist()]  # unscaled inverse
 
 
-def prepared(emu, params, bsk):
+def test_fp_field_arithmetic(emu):
+    """fp64 field: mul/reduce/to_u32 against Python integers, including the magnitudes the
+    transforms can reach (|a| up to 2^52.9, |w| <= p/2)."""
+    p = int(emu.emu_fp_p())
+    assert p == (1 << 42) - 24575
+    rng = np.random.default_rng(1)
+    n = 200000
+    a = rng.integers(-(1 << 52), 1 << 52, size=n).astype(np.float64)
+    a[:8] = [0, 1, -1, (1 << 53) - 2, -((1 << 53) - 2), p, -p, (p - 1) // 2]
+    a[8:1000] = rng.integers(-(1 << 53) + 2, (1 << 53) - 2, size=992).astype(np.float64)
+    w = rng.integers(-(p // 2), p // 2 + 1, size=n).astype(np.float64)
+    w[:4] = [p // 2, -(p // 2), 1, -1]
+    out = np.zeros(n)
+    emu.emu_fp_mul_many(pd(a), pd(w), pd(out), C.c_size_t(n))
+    ai, wi, oi = [int(x) for x in a], [int(x) for x in w], [int(x) for x in out]
+    assert all(float(o) == fo for o, fo in zip(oi, out))               # integer valued
+    assert all((o - x * y) % p == 0 for o, x, y in zip(oi, ai, wi))    # congruent
+    bound = [p / 2 + 1.5 * abs(x) * p / 2 ** 53 + 2 for x in ai]
+    assert all(abs(o) <= b for o, b in zip(oi, bound))                 # growth bound used in field_fp.h
+    red = np.zeros(n)
+    emu.emu_fp_reduce_many(pd(a), pd(red), C.c_size_t(n))
+    assert all((int(r) - x) % p == 0 and abs(int(r)) <= p // 2 + 1 for r, x in zip(red, ai))
+    t = rng.integers(-(1 << 52), 1 << 52, size=n).astype(np.float64)
+    t[:6] = [0, -1, (1 << 32), -(1 << 32), (1 << 32) - 1, -(1 << 31)]
+    u = np.zeros(n, dtype=np.uint32)
+    emu.emu_fp_to_u32_many(pd(t), p32(u), C.c_size_t(n))
+    assert u.tolist() == [int(x) % (1 << 32) for x in t]
+    for word in (0, 1, 0x7FFF, 0x8000, 0xFFFF, 0x10000, 0x7FFFFFFF, 0x80000000, 0xFFFFFFFF, 0x8000FFFF, 0x12348765):
+        lo = emu.emu_fp_from_key_word(C.c_uint32(word), 0)
+        hi = emu.emu_fp_from_key_word(C.c_uint32(word), 1)
+        assert abs(lo) <= 1 << 15 and abs(hi) <= 1 << 15
+        assert (int(lo) + (int(hi) << 16) - word) % (1 << 32) == 0
+
+
+@pytest.mark.parametrize("logn", [9, 10, 11])
+def test_fp_wave_ntt_roundtrip_and_convolution(emu, logn):
+    """fp64 field transform: forward of two small polynomials, pointwise product, inverse = exact
+    negacyclic convolution (checked with numpy integers)."""
+    n = 1 << logn
+    p = int(emu.emu_fp_p())
+    rng = np.random.default_rng(logn)
+    a = rng.integers(-256, 257, size=n).astype(np.float64)
+    b = rng.integers(-(1 << 15), (1 << 15) + 1, size=n).astype(np.float64)
+    fa, fb = np.zeros(n), np.zeros(n)
+    assert emu.emu_poly_ntt(FP, logn, pd(a), pd(fa), 0) == 0
+    assert emu.emu_poly_ntt(FP, logn, pd(b), pd(fb), 0) == 0
+    assert np.abs(fa).max() <= 6.2 * p and np.abs(fb).max() <= 6.2 * p
+    ninv = pow(n, p - 2, p)
+    prod = np.array([float(((int(x) * int(y) % p) * ninv) % p) for x, y in zip(fa, fb)])
+    prod = np.where(prod > p // 2, prod - p, prod)
+    back = np.zeros(n)
+    assert emu.emu_poly_ntt(FP, logn, pd(prod), pd(back), 1) == 0
+    assert np.abs(back).max() < 2 ** 53
+    ai, bi = a.astype(np.int64), b.astype(np.int64)
+    full = np.convolve(ai, bi)
+    want = full[:n].copy()
+    want[: n - 1] -= full[n:]
+    got = np.array([int(x) % p for x in back])
+    assert np.array_equal(got, want % p)
+
+
+def prepared(emu, field, params, bsk):
     flat = np.ascontiguousarray(bsk, dtype=np.uint32).reshape(-1, params.N)
-    out = np.zeros(flat.shape, dtype=np.uint64)
-    assert emu.emu_bsk_prepare(params.glwe_poly_degree, C.c_size_t(flat.shape[0]), p32(flat), p64(out)) == 0
+    parts = emu.emu_field_parts(field)
+    out = np.zeros((flat.shape[0], parts, params.N), dtype=np.uint64)
+    assert emu.emu_bsk_prepare(field, params.glwe_poly_degree, C.c_size_t(flat.shape[0]), p32(flat), p64(out)) == 0
     return out
 
 
@@ -104,22 +176,58 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("field", FIELDS)
 @pytest.mark.parametrize("k,logn,n,pbs,log_p", CASES)
-def test_external_product_vs_oracle(emu, oracle, k, logn, n, pbs, log_p):
+def test_external_product_vs_oracle(emu, oracle, field, k, logn, n, pbs, log_p):
     params = oracle.Params(k, logn, n, oracle.Decomposer(*pbs), log_p=log_p)
     rng = np.random.default_rng(11 * logn + k)
     ggsw = rng.integers(0, 1 << 32, size=(params.R, k + 1, params.N), dtype=np.uint64).astype(np.uint32)
     glwe = rng.integers(0, 1 << 32, size=(k + 1, params.N), dtype=np.uint64).astype(np.uint32)
     # hit the digit == B and digit == -B/2 paths in every polynomial
     glwe[:, :4] = [0xFFFFFFFF, 0x7FFFFFFF, 0x80000000, 0xF8F8F8F8]
-    spec = prepared(emu, params, ggsw)
+    spec = prepared(emu, field, params, ggsw)
     out = np.zeros_like(glwe)
-    assert emu.emu_external_product(k, logn, pbs[0], pbs[1], p64(spec), p32(glwe), p32(out)) == 0
+    assert emu.emu_external_product(field, k, logn, pbs[0], pbs[1], p64(spec), p32(glwe), p32(out)) == 0
     assert np.array_equal(out, oracle.external_product(params, ggsw, glwe))
 
 
+@pytest.mark.parametrize("field", FIELDS)
+@pytest.mark.parametrize("k,logn,pbs", [(1, 10, (7, 3)), (2, 11, (8, 4)), (2, 9, (4, 6)), (1, 9, (16, 2))])
+def test_external_product_worst_case_magnitudes(emu, oracle, field, k, logn, pbs):
+    """Adversarial inputs that drive the integer convolution to its bound: every digit at +B or
+    -B/2 and every key word at 0x7FFF8000-type extremes (both 16-bit halves maximal), aligned so
+    that the negacyclic sums do not cancel.  The exact-NTT bound must hold, not just typical inputs."""
+    params = oracle.Params(k, logn, 1, oracle.Decomposer(*pbs))
+    log_base, levels = pbs
+    N = params.N
+    if field == FP and np.log2(params.R) + logn + log_base + 15 >= 40.9:
+        pytest.skip("outside the fp64 field's exactness bound: the context selects Goldilocks here")
+    first_shift = log_base * (32 // log_base - levels)
+    # word whose every kept limb is B-1 with an incoming carry -> digits B ... (top ones), built by brute force
+    def word_with_digits(target):
+        rng = np.random.default_rng(7)
+        best, best_score = 0, -1
+        cand = np.concatenate([rng.integers(0, 1 << 32, size=200000, dtype=np.uint64).astype(np.uint32),
+                               np.array([0xFFFFFFFF, 0x7FFFFFFF, 0xF8F8F8F8, 0xFFFFFF80], dtype=np.uint32)])
+        d = oracle.decompose(oracle.Decomposer(*pbs), cand).astype(np.int32).astype(np.int64)
+        score = (d * target).sum(axis=1)
+        return int(cand[int(score.argmax())])
+    wpos = word_with_digits(+1)
+    wneg = word_with_digits(-1)
+    for key_word, glwe_word in ((0x7FFF7FFF, wpos), (0x80008000, wpos), (0x7FFF8000, wneg), (0xFFFFFFFF, wneg)):
+        ggsw = np.full((params.R, k + 1, N), key_word, dtype=np.uint32)
+        glwe = np.full((k + 1, N), glwe_word, dtype=np.uint32)
+        # negacyclic sign pattern: make the key alternate sign across the wrap so sums add up at coefficient 0
+        ggsw[:, :, 1:] = (np.uint32(0) - ggsw[:, :, 1:]).astype(np.uint32)
+        spec = prepared(emu, field, params, ggsw)
+        out = np.zeros_like(glwe)
+        assert emu.emu_external_product(field, k, logn, log_base, levels, p64(spec), p32(glwe), p32(out)) == 0
+        assert np.array_equal(out, oracle.external_product(params, ggsw, glwe)), hex(key_word)
+
+
+@pytest.mark.parametrize("field", FIELDS)
 @pytest.mark.parametrize("k,logn,n,pbs,log_p", CASES)
-def test_blind_rotate_and_extract_vs_oracle(emu, oracle, k, logn, n, pbs, log_p):
+def test_blind_rotate_and_extract_vs_oracle(emu, oracle, field, k, logn, n, pbs, log_p):
     params = oracle.Params(k, logn, n, oracle.Decomposer(*pbs), log_p=log_p)
     batch = 2
     lut = np.random.default_rng(5).integers(0, 1 << log_p, size=1 << log_p)
@@ -127,10 +235,10 @@ def test_blind_rotate_and_extract_vs_oracle(emu, oracle, k, logn, n, pbs, log_p)
     lwe = lwe.copy()
     lwe[0, 0] = 0            # a~ = 0: the skipped iteration
     lwe[1, n] = 0xFFFFFFFF   # b~ rounds up to 2N and wraps to 0
-    spec = prepared(emu, params, bsk)
+    spec = prepared(emu, field, params, bsk)
     glwe = np.zeros((batch, k + 1, params.N), dtype=np.uint32)
     ext = np.zeros((batch, params.big_n + 1), dtype=np.uint32)
-    rc = emu.emu_blind_rotate(n, k, logn, log_p, 1, pbs[0], pbs[1], C.c_size_t(batch), p32(lwe), p32(tv),
+    rc = emu.emu_blind_rotate(field, n, k, logn, log_p, 1, pbs[0], pbs[1], C.c_size_t(batch), p32(lwe), p32(tv),
                               C.c_size_t(0), p64(spec), p32(glwe), p32(ext))
     assert rc == 0
     for b in range(batch):

@@ -22,34 +22,53 @@ def make(oracle, k, logn, n, pbs, ks, log_p):
     return oracle.Params(k, logn, n, oracle.Decomposer(*pbs), oracle.Decomposer(*ks), log_p=log_p)
 
 
+BACKENDS = ["fp64", "goldilocks"]
+
+
+def backend_id(name):
+    m = pkg()
+    return {"fp64": m.BACKEND_FP64, "goldilocks": m.BACKEND_GOLDILOCKS, "auto": m.BACKEND_AUTO}[name]
+
+
+def fp64_exact(p):
+    """the fp64 backend's exactness bound (tfhe_hip.h): (k+1) l N B 2^15 < 2^40.9"""
+    return np.log2(p.R) + p.glwe_poly_degree + p.pbs.log_base + 15 < 40.9
+
+
 @pytest.fixture(scope="module")
 def contexts(oracle):
     made = {}
 
-    def get(name):
-        if name not in made:
+    def get(name, backend="auto"):
+        key = (name, backend)
+        name_key = name
+        if key not in made:
             spec = next(s for s in SHAPES if s[0] == name)
             p = make(oracle, *spec[1:])
             batch = 9  # not a multiple of the waves per workgroup: exercises the ragged tail
             lut = np.random.default_rng(len(name)).integers(0, 1 << p.log_p, size=1 << p.log_p)
-            lwe, bsk, ksk, tv = oracle.synthetic_inputs(p, batch, cfg_index=70 + len(made), lut=lut)
+            lwe, bsk, ksk, tv = oracle.synthetic_inputs(p, batch, cfg_index=70 + len(name), lut=lut)
             lwe = lwe.copy()
             lwe[0, 0] = 0             # a~ = 0 -> skipped CMUX
             lwe[1, p.n] = 0xFFFFFFFF  # b~ rounds to 2N and wraps to 0
             lwe[2, :] = 0x80000000
-            ctx = pkg().Context(to_pkg_params(p))
+            if backend == "fp64" and not fp64_exact(p):
+                pytest.skip("outside the fp64 backend's exactness bound")
+            ctx = pkg().Context(to_pkg_params(p), backend=backend_id(backend))
             ctx.load_bootstrapping_key(bsk, ksk)
-            made[name] = (p, ctx, lwe, bsk, ksk, tv)
-        return made[name]
+            made[key] = (p, ctx, lwe, bsk, ksk, tv)
+        return made[key]
 
     yield get
     for _, ctx, *_ in made.values():
         ctx.close()
 
 
+@pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("name", [s[0] for s in SHAPES])
-def test_bootstrap_matches_oracle(oracle, contexts, name):
-    p, ctx, lwe, bsk, ksk, tv = contexts(name)
+def test_bootstrap_matches_oracle(oracle, contexts, name, backend):
+    p, ctx, lwe, bsk, ksk, tv = contexts(name, backend)
+    assert ctx.backend.startswith(backend[:4])
     got = ctx.bootstrap(lwe, tv)
     glwe = ctx.blind_rotate(lwe, tv)
     for b in range(lwe.shape[0]):
@@ -65,15 +84,18 @@ def test_bootstrap_matches_oracle(oracle, contexts, name):
     assert np.array_equal(ctx.bootstrap(lwe[4], tv), got[4])
 
 
+@pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("name", [s[0] for s in SHAPES])
-def test_external_product_and_cmux(oracle, contexts, name):
-    p, ctx, *_ = contexts(name)
+def test_external_product_and_cmux(oracle, contexts, name, backend):
+    p, ctx, *_ = contexts(name, backend)
     rng = np.random.default_rng(3)
     batch = 5
     ggsw = rand_u32(rng, (batch, p.R, p.k + 1, p.N))
     ct0 = rand_u32(rng, (batch, p.k + 1, p.N))
     ct1 = rand_u32(rng, (batch, p.k + 1, p.N))
     ct0[:, :, :4] = [0xFFFFFFFF, 0x7FFFFFFF, 0x80000000, 0xF8F8F8F8]
+    # extreme key words: both signed 16-bit halves at their bounds
+    ggsw[0, :, :, :6] = [0x7FFF7FFF, 0x80008000, 0x7FFF8000, 0xFFFFFFFF, 0x00008000, 0x80000000]
     # one GGSW per sample
     got = ctx.external_product(ggsw, ct0)
     for b in range(batch):
@@ -178,15 +200,33 @@ def test_error_behaviour(oracle):
 
 
 def test_full_size_cfg2_sample_parity(oracle):
-    """BASELINE cfg2 at full size (N=1024, k=1, n=630, l=3, logB=7): a batch of 64 on the GPU, three
-    samples checked against the oracle end to end (each oracle PBS is ~8 G u32 MACs)."""
+    """BASELINE cfg2 at full size (N=1024, k=1, n=630, l=3, logB=7): a batch of 64 on the GPU with
+    both backends, three samples checked against the oracle end to end (each oracle PBS is ~8 G u32
+    MACs), and the two backends against each other on the whole batch."""
     p = oracle.CFG2
     lwe, bsk, ksk, tv = oracle.synthetic_inputs(p, 64, cfg_index=2)
     m = pkg()
-    with m.Context(to_pkg_params(p)) as ctx:
-        ctx.load_bootstrapping_key(bsk, ksk)
-        out = ctx.bootstrap(lwe, tv)
-        # determinism: same inputs, same bits
-        assert np.array_equal(out, ctx.bootstrap(lwe, tv))
+    outs = {}
+    for backend in BACKENDS:
+        with m.Context(to_pkg_params(p), backend=backend_id(backend)) as ctx:
+            ctx.load_bootstrapping_key(bsk, ksk)
+            outs[backend] = ctx.bootstrap(lwe, tv)
+            # determinism: same inputs, same bits
+            assert np.array_equal(outs[backend], ctx.bootstrap(lwe, tv))
+    assert np.array_equal(outs["fp64"], outs["goldilocks"])
     for b in (0, 31, 63):
-        assert np.array_equal(out[b], oracle.bootstrap(p, lwe[b], bsk, ksk, tv)), b
+        assert np.array_equal(outs["fp64"][b], oracle.bootstrap(p, lwe[b], bsk, ksk, tv)), b
+
+
+def test_backend_selection(oracle):
+    """AUTO picks fp64 when (k+1) l N B 2^15 < 2^40.9 and Goldilocks otherwise; forcing fp64 outside
+    its bound is refused (TFHE_ERR_EXACTNESS)."""
+    m = pkg()
+    with m.Context(to_pkg_params(oracle.CFG2)) as ctx:
+        assert ctx.backend == "fp64-p42"
+    wide = m.TfheParams(1, 11, 2, m.DecomposerParams(16, 2))  # 2 * 2048 * 2^16 * 2^15 = 2^43
+    with m.Context(wide) as ctx:
+        assert ctx.backend == "goldilocks"
+    with pytest.raises(m.TfheError) as e:
+        m.Context(wide, backend=m.BACKEND_FP64)
+    assert e.value.status == 7

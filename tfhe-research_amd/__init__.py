@@ -18,7 +18,7 @@ from dataclasses import dataclass, field
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtfhe_hip.so")
+LIB_PATH = os.environ.get("TFHE_HIP_LIB") or os.path.join(_HERE, "libtfhe_hip.so")  # env: dev builds only
 
 TFHE_OK = 0
 STATUS_NAMES = {
@@ -26,6 +26,7 @@ STATUS_NAMES = {
     4: "TFHE_ERR_HIP", 5: "TFHE_ERR_INVALID_ARGUMENT", 6: "TFHE_ERR_NO_DEVICE", 7: "TFHE_ERR_EXACTNESS",
 }
 DECOMPOSER_PBS, DECOMPOSER_KS = 0, 1
+BACKEND_AUTO, BACKEND_GOLDILOCKS, BACKEND_FP64 = 0, 1, 2
 
 # truth[(lhs << 1) | rhs]
 GATE_AND = (0, 0, 0, 1)
@@ -118,6 +119,28 @@ def library_available() -> bool:
     return os.path.exists(LIB_PATH)
 
 
+def _preload_torch_hip_runtime():
+    """PyTorch wheels bundle their own libamdhip64.so.  Two HIP runtimes in one process cannot both
+    own the GPU (the second one reports "no ROCm-capable device"), so when torch is installed its
+    copy is loaded first and our library binds to it by SONAME, whatever the import order."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """The HIP shared library.  Fails loudly when it has not been built."""
     global _lib
@@ -126,6 +149,7 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with __graft_entry__.build() "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        _preload_torch_hip_runtime()
         _lib = C.CDLL(LIB_PATH)
         _lib.tfhe_last_error.restype = C.c_char_p
         _lib.tfhe_status_string.restype = C.c_char_p
@@ -186,11 +210,13 @@ def params_validate(params: TfheParams) -> int:
 class Context:
     """One GPU context = one device + one stream + one loaded BootstrappingKey."""
 
-    def __init__(self, params: TfheParams, device: int = 0):
+    def __init__(self, params: TfheParams, device: int = 0, backend: int = BACKEND_AUTO):
         self.params = params
         self._h = C.c_void_p()
         cp = params._c()
-        st = lib().tfhe_context_create(C.byref(cp), C.c_int(device), C.byref(self._h))
+        lib().tfhe_context_backend.restype = C.c_char_p
+        st = lib().tfhe_context_create_with_backend(C.byref(cp), C.c_int(device), C.c_int(backend),
+                                                    C.byref(self._h))
         if st:
             self._h = C.c_void_p()
             raise TfheError(st, lib().tfhe_status_string(st).decode())
@@ -216,6 +242,15 @@ class Context:
     def _check(self, st: int):
         if st:
             raise TfheError(st, lib().tfhe_last_error(self._h).decode())
+
+    @property
+    def backend(self) -> str:
+        return lib().tfhe_context_backend(self._h).decode()
+
+    def prepared_ggsw_words(self) -> int:
+        w = C.c_size_t()
+        self._check(lib().tfhe_prepared_ggsw_words(self._h, C.byref(w)))
+        return w.value
 
     def set_stream(self, hip_stream: int | None):
         self._check(lib().tfhe_context_set_stream(self._h, C.c_void_p(hip_stream or 0)))
@@ -332,8 +367,8 @@ class Context:
     def prepare_ggsw_device(self, ggsw):
         """device u32 GGSW(s) -> device NTT-domain GGSW(s) (torch int64 tensor)."""
         import torch
-        out = torch.empty(tuple(ggsw.shape), dtype=torch.int64, device=ggsw.device)
         count = 1 if ggsw.dim() == 3 else ggsw.shape[0]
+        out = torch.empty((count, self.prepared_ggsw_words()), dtype=torch.int64, device=ggsw.device)
         self._check(lib().tfhe_prepare_ggsw_device(self._h, _dp(ggsw), C.c_size_t(count),
                                                    C.c_void_p(out.data_ptr())))
         return out
@@ -342,7 +377,7 @@ class Context:
         import torch
         p = self.params
         batch = glwe.shape[0]
-        count = 1 if ggsw_prepared.dim() == 3 else ggsw_prepared.shape[0]
+        count = ggsw_prepared.shape[0]
         if out is None:
             out = torch.empty_like(glwe)
         self._check(lib().tfhe_external_product_prepared_device(

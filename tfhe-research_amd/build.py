@@ -36,7 +36,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     """hipcc --offload-arch=gfx950 -> tfhe-research_amd/libtfhe_hip.so"""
     if not force and not is_stale():
         return LIB
-    cmd = [_hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
+    cmd = [_hipcc(), "-O3", "-std=c++17", "-ffp-contract=off", "--offload-arch=gfx950", "-fPIC", "-shared",
+           "-DTFHE_WAVES_PER_SIMD_FP=2", "-DTFHE_WAVES_PER_SIMD_GL=2",
            "-I", os.path.join(ROOT, "include"), "-I", CSRC]
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     cmd += ["-o", LIB + ".tmp"]

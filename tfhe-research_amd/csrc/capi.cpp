@@ -9,6 +9,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -27,8 +28,10 @@ struct tfhe_context {
   bool own_stream = false;
   u32 N = 0, R = 0, big_n = 0;
 
-  u64* d_tw = nullptr;        // psi_rev[N]
-  u64* d_bsk = nullptr;       // prepared BSK [n][R][k+1][N] u64 (spectrum_slot order, x 1/N)
+  int field = 0;              // launch::kFieldGoldilocks | launch::kFieldFp64
+  int parts = 1;              // spectra per key polynomial in this field
+  void* d_tw = nullptr;       // psi_rev[N], 8-byte field elements
+  void* d_bsk = nullptr;      // prepared BSK [n][R][k+1][parts][N] (spectrum_slot order, x 1/N)
   u32* d_ksk = nullptr;       // [big_n*l_ks][n+1]
   bool have_key = false;
 
@@ -46,7 +49,7 @@ struct tfhe_context {
   // generic scratch for the small entry points
   void* d_misc = nullptr;
   size_t misc_bytes = 0;
-  u64* d_ggsw_tmp = nullptr;  // prepared GGSWs of external_product / cmux host calls
+  u64* d_ggsw_tmp = nullptr;  // prepared GGSWs of external_product / cmux host calls (8-byte words)
   size_t ggsw_tmp_words = 0;
   u32* d_ggsw_raw = nullptr;
   size_t ggsw_raw_words = 0;
@@ -162,7 +165,7 @@ int check_tv_host(tfhe_context* ctx, const u32* tv, size_t words) {
 int enqueue_bootstrap(tfhe_context* ctx, const u32* d_lwe_in, size_t batch, const u32* d_tv,
                       size_t tv_count, u32* d_lwe_big, u32* d_lwe_out) {
   if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-  HIP_TRY(ctx, launch::blind_rotate(ctx->stream, ctx->pbs, ctx->d_tw, d_lwe_in, batch, d_tv,
+  HIP_TRY(ctx, launch::blind_rotate(ctx->stream, ctx->field, ctx->pbs, ctx->d_tw, d_lwe_in, batch, d_tv,
                                     tv_count == 1 ? 0 : ctx->N, ctx->d_bsk, nullptr, d_lwe_big));
   if (ctx->timing) {
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
@@ -190,11 +193,27 @@ size_t ggsw_words(const tfhe_context* ctx) {
   return (size_t)ctx->R * (ctx->params.glwe_dimension + 1) * ctx->N;
 }
 
+// log2 of the worst-case |integer convolution value| one inverse transform has to lift:
+// R * N * max|digit| (= B, decomposer.rs:54-63) * max|key operand|
+double convolution_bits(const tfhe_params* p, double key_bits) {
+  return std::log2((double)(p->glwe_dimension + 1) * p->pbs_decomposer.levels) + p->glwe_poly_degree +
+         p->pbs_decomposer.log_base + key_bits;
+}
+
+template <class F>
+hipError_t upload_twiddles(tfhe_context* ctx) {
+  std::vector<typename F::elem> tw(ctx->N);
+  F::fill_twiddles((int)ctx->params.glwe_poly_degree, tw.data());
+  hipError_t e = hipMalloc(&ctx->d_tw, ctx->N * sizeof(typename F::elem));
+  if (e != hipSuccess) return e;
+  return hipMemcpy(ctx->d_tw, tw.data(), ctx->N * sizeof(typename F::elem), hipMemcpyHostToDevice);
+}
+
 }  // namespace
 
 extern "C" {
 
-const char* tfhe_version(void) { return "tfhe-research_amd 0.1 (gfx950, goldilocks-ntt)"; }
+const char* tfhe_version(void) { return "tfhe-research_amd 0.2 (gfx950; exact NTT backends: fp64-p42, goldilocks)"; }
 
 const char* tfhe_status_string(int status) {
   switch (status) {
@@ -235,19 +254,29 @@ int tfhe_params_validate(const tfhe_params* p) {
 
 const char* tfhe_last_error(const tfhe_context* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
 
-int tfhe_context_create(const tfhe_params* params, int device, tfhe_context** out) {
+int tfhe_context_create_with_backend(const tfhe_params* params, int device, int backend,
+                                     tfhe_context** out) {
   if (!params || !out) return TFHE_ERR_INVALID_ARGUMENT;
   *out = nullptr;
   int st = tfhe_params_validate(params);
   if (st != TFHE_OK) return st;
   if (!launch::shape_supported(params->glwe_poly_degree, params->glwe_dimension))
     return TFHE_ERR_UNSUPPORTED;
-  // exactness of the integer convolution in F_p: R * N * max|digit| * 2^32 < p/2 ~ 2^63
-  {
-    const double bits = std::log2((double)(params->glwe_dimension + 1) * params->pbs_decomposer.levels) +
-                        params->glwe_poly_degree + params->pbs_decomposer.log_base + 32.0;
-    if (bits >= 62.0) return TFHE_ERR_EXACTNESS;
+  // exactness of the integer convolution in the chosen field
+  const bool fp_ok = convolution_bits(params, FpField::key_bits()) < FpField::exact_bits();
+  const bool gl_ok = convolution_bits(params, GlField::key_bits()) < GlField::exact_bits();
+  int field = 0;
+  if (backend == TFHE_BACKEND_AUTO) {
+    const char* env = std::getenv("TFHE_HIP_BACKEND");
+    if (env && std::strcmp(env, "goldilocks") == 0) backend = TFHE_BACKEND_GOLDILOCKS;
+    else if (env && std::strcmp(env, "fp64") == 0) backend = TFHE_BACKEND_FP64;
   }
+  if (backend == TFHE_BACKEND_AUTO) field = fp_ok ? launch::kFieldFp64 : launch::kFieldGoldilocks;
+  else if (backend == TFHE_BACKEND_GOLDILOCKS) field = launch::kFieldGoldilocks;
+  else if (backend == TFHE_BACKEND_FP64) field = launch::kFieldFp64;
+  else return TFHE_ERR_INVALID_ARGUMENT;
+  if ((field == launch::kFieldFp64 && !fp_ok) || (field == launch::kFieldGoldilocks && !gl_ok))
+    return TFHE_ERR_EXACTNESS;
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count)
     return TFHE_ERR_NO_DEVICE;
@@ -256,6 +285,8 @@ int tfhe_context_create(const tfhe_params* params, int device, tfhe_context** ou
   if (!ctx) return TFHE_ERR_HIP;
   ctx->params = *params;
   ctx->device = device;
+  ctx->field = field;
+  ctx->parts = launch::field_parts(field);
   ctx->N = 1u << params->glwe_poly_degree;
   ctx->R = (params->glwe_dimension + 1) * params->pbs_decomposer.levels;
   ctx->big_n = ctx->N * params->glwe_dimension;  // lib.rs:60
@@ -285,16 +316,26 @@ int tfhe_context_create(const tfhe_params* params, int device, tfhe_context** ou
   ctx->own_stream = true;
   for (auto& ev : ctx->ev)
     if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e, "hipEventCreate");
-
-  std::vector<u64> tw(ctx->N);
-  ntt_fill_twiddles((int)params->glwe_poly_degree, tw.data());
-  if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->d_tw), ctx->N * sizeof(u64))) != hipSuccess)
-    return bail(e, "hipMalloc twiddles");
-  if ((e = hipMemcpy(ctx->d_tw, tw.data(), ctx->N * sizeof(u64), hipMemcpyHostToDevice)) != hipSuccess)
-    return bail(e, "hipMemcpy twiddles");
+  e = field == launch::kFieldFp64 ? upload_twiddles<FpField>(ctx) : upload_twiddles<GlField>(ctx);
+  if (e != hipSuccess) return bail(e, "twiddle upload");
   if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->d_tv_gate), ctx->N * sizeof(u32))) != hipSuccess)
     return bail(e, "hipMalloc gate tv");
   *out = ctx;
+  return TFHE_OK;
+}
+
+int tfhe_context_create(const tfhe_params* params, int device, tfhe_context** out) {
+  return tfhe_context_create_with_backend(params, device, TFHE_BACKEND_AUTO, out);
+}
+
+const char* tfhe_context_backend(const tfhe_context* ctx) {
+  if (!ctx) return "";
+  return ctx->field == launch::kFieldFp64 ? "fp64-p42" : "goldilocks";
+}
+
+int tfhe_prepared_ggsw_words(const tfhe_context* ctx, size_t* words) {
+  if (!ctx || !words) return TFHE_ERR_INVALID_ARGUMENT;
+  *words = ggsw_words(ctx) * ctx->parts;
   return TFHE_OK;
 }
 
@@ -371,10 +412,10 @@ static int load_key_common(tfhe_context* ctx, const u32* d_bsk_raw, const u32* d
   const size_t bsk_polys = (size_t)ctx->params.lwe_dimension * ctx->R * (ctx->params.glwe_dimension + 1);
   const size_t ksk_words = (size_t)ctx->big_n * ctx->ks.levels * ((size_t)ctx->params.lwe_dimension + 1);
   if (!ctx->d_bsk)
-    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_bsk), bsk_polys * ctx->N * sizeof(u64)));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_bsk, bsk_polys * ctx->parts * ctx->N * sizeof(u64)));
   if (!ctx->d_ksk)
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_ksk), ksk_words * sizeof(u32)));
-  HIP_TRY(ctx, launch::bsk_prepare(ctx->stream, ctx->pbs.log_n, ctx->d_tw, d_bsk_raw, bsk_polys, ctx->d_bsk));
+  HIP_TRY(ctx, launch::bsk_prepare(ctx->stream, ctx->field, ctx->pbs.log_n, ctx->d_tw, d_bsk_raw, bsk_polys, ctx->d_bsk));
   if (ksk_needs_copy)
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_ksk, d_ksk_raw, ksk_words * sizeof(u32),
                                 hipMemcpyDeviceToDevice, ctx->stream));
@@ -447,7 +488,7 @@ int tfhe_blind_rotate_batch_device(tfhe_context* ctx, const uint32_t* lwe_in, si
   if ((st = check_batch_args(ctx, lwe_in, tv, glwe_out, batch, tv_count))) return st;
   if (!ctx->have_key) return fail(ctx, TFHE_ERR_NO_KEY, "load the bootstrapping key first");
   if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-  HIP_TRY(ctx, launch::blind_rotate(ctx->stream, ctx->pbs, ctx->d_tw, lwe_in, batch, tv,
+  HIP_TRY(ctx, launch::blind_rotate(ctx->stream, ctx->field, ctx->pbs, ctx->d_tw, lwe_in, batch, tv,
                                     tv_count == 1 ? 0 : ctx->N, ctx->d_bsk, glwe_out, nullptr));
   if (ctx->timing) {
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
@@ -527,17 +568,16 @@ int tfhe_key_switch_batch(tfhe_context* ctx, const uint32_t* lwe_in, size_t batc
 
 // ---------------------------------------------------------------------------------- ggsw.rs
 int tfhe_prepare_ggsw_device(tfhe_context* ctx, const uint32_t* ggsw, size_t ggsw_count,
-                             uint64_t* ggsw_prepared) {
+                             void* ggsw_prepared) {
   int st = check_ctx(ctx);
   if (st) return st;
   if (!ggsw || !ggsw_prepared || ggsw_count == 0) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer / zero count");
   const size_t polys = ggsw_count * ctx->R * (ctx->params.glwe_dimension + 1);
-  HIP_TRY(ctx, launch::bsk_prepare(ctx->stream, ctx->pbs.log_n, ctx->d_tw, ggsw, polys,
-                                   reinterpret_cast<u64*>(ggsw_prepared)));
+  HIP_TRY(ctx, launch::bsk_prepare(ctx->stream, ctx->field, ctx->pbs.log_n, ctx->d_tw, ggsw, polys, ggsw_prepared));
   return TFHE_OK;
 }
 
-int tfhe_external_product_prepared_device(tfhe_context* ctx, const uint64_t* ggsw_prepared,
+int tfhe_external_product_prepared_device(tfhe_context* ctx, const void* ggsw_prepared,
                                           size_t ggsw_count, const uint32_t* glwe_in, size_t batch,
                                           uint32_t* glwe_out) {
   int st = check_ctx(ctx);
@@ -547,10 +587,9 @@ int tfhe_external_product_prepared_device(tfhe_context* ctx, const uint64_t* ggs
   if (ggsw_count != 1 && ggsw_count != batch)
     return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "ggsw_count must be 1 or batch");
   if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-  HIP_TRY(ctx, launch::external_product(ctx->stream, ctx->pbs, ctx->d_tw,
-                                        reinterpret_cast<const u64*>(ggsw_prepared),
-                                        ggsw_count == 1 ? 0 : ggsw_words(ctx), glwe_in, nullptr, nullptr,
-                                        batch, glwe_out));
+  HIP_TRY(ctx, launch::external_product(ctx->stream, ctx->field, ctx->pbs, ctx->d_tw, ggsw_prepared,
+                                        ggsw_count == 1 ? 0 : ggsw_words(ctx) * ctx->parts, glwe_in,
+                                        nullptr, nullptr, batch, glwe_out));
   if (ctx->timing) {
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     ctx->ev_valid_br = true;
@@ -563,9 +602,9 @@ static int upload_and_prepare_ggsw(tfhe_context* ctx, const u32* ggsw, size_t gg
   const size_t words = ggsw_count * ggsw_words(ctx);
   int st;
   if ((st = ensure(ctx, &ctx->d_ggsw_raw, &ctx->ggsw_raw_words, words))) return st;
-  if ((st = ensure(ctx, &ctx->d_ggsw_tmp, &ctx->ggsw_tmp_words, words))) return st;
+  if ((st = ensure(ctx, &ctx->d_ggsw_tmp, &ctx->ggsw_tmp_words, words * ctx->parts))) return st;
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_ggsw_raw, ggsw, words * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
-  return tfhe_prepare_ggsw_device(ctx, ctx->d_ggsw_raw, ggsw_count, reinterpret_cast<uint64_t*>(ctx->d_ggsw_tmp));
+  return tfhe_prepare_ggsw_device(ctx, ctx->d_ggsw_raw, ggsw_count, ctx->d_ggsw_tmp);
 }
 
 int tfhe_external_product_batch(tfhe_context* ctx, const uint32_t* ggsw, size_t ggsw_count,
@@ -578,7 +617,7 @@ int tfhe_external_product_batch(tfhe_context* ctx, const uint32_t* ggsw, size_t 
   if ((st = upload_and_prepare_ggsw(ctx, ggsw, ggsw_count))) return st;
   const size_t glwe = (size_t)(ctx->params.glwe_dimension + 1) * ctx->N;
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_glwe_a, glwe_in, batch * glwe * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
-  if ((st = tfhe_external_product_prepared_device(ctx, reinterpret_cast<uint64_t*>(ctx->d_ggsw_tmp), ggsw_count,
+  if ((st = tfhe_external_product_prepared_device(ctx, ctx->d_ggsw_tmp, ggsw_count,
                                                   ctx->d_glwe_a, batch, ctx->d_glwe_b)))
     return st;
   HIP_TRY(ctx, hipMemcpyAsync(glwe_out, ctx->d_glwe_b, batch * glwe * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
@@ -597,9 +636,9 @@ int tfhe_cmux_batch(tfhe_context* ctx, const uint32_t* ggsw, size_t ggsw_count, 
   const size_t glwe = (size_t)(ctx->params.glwe_dimension + 1) * ctx->N;
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_glwe_a, ct0, batch * glwe * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_glwe_b, ct1, batch * glwe * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, launch::external_product(ctx->stream, ctx->pbs, ctx->d_tw, ctx->d_ggsw_tmp,
-                                        ggsw_count == 1 ? 0 : ggsw_words(ctx), nullptr, ctx->d_glwe_b,
-                                        ctx->d_glwe_a, batch, ctx->d_glwe_c));
+  HIP_TRY(ctx, launch::external_product(ctx->stream, ctx->field, ctx->pbs, ctx->d_tw, ctx->d_ggsw_tmp,
+                                        ggsw_count == 1 ? 0 : ggsw_words(ctx) * ctx->parts, nullptr,
+                                        ctx->d_glwe_b, ctx->d_glwe_a, batch, ctx->d_glwe_c));
   HIP_TRY(ctx, hipMemcpyAsync(glwe_out, ctx->d_glwe_c, batch * glwe * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(ct1, ctx->d_glwe_b, batch * glwe * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

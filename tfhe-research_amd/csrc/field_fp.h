@@ -1,0 +1,93 @@
+// field_fp.h -- field policy: F_p with p = 2^42 - 24575 (prime, p - 1 = 2^13 * 536870909),
+// elements are IEEE doubles holding exact integers.
+//
+// Why: on gfx950 fp64 FMA/mul/add/rndne issue at the same ~4.5 cycles per wave as every integer
+// op (profiles/r01_valu_issue_rates_gfx950.txt), and a modular butterfly costs 8 fp64
+// instructions here against ~46 integer instructions for Goldilocks.
+//
+// Exactness (all values are integers, |twiddle|, |key spectrum| <= p/2 < 2^41):
+//   mul(a, w), |a| < 2^53:  h = RN(a*w), l = a*w - h exactly (FMA), q = rint(RN(h/p)) is within 1
+//     of h/p, so h - q*p is an integer of magnitude <= 1.5p + |a w| 2^-52 < 2^53: the FMA returns
+//     it exactly, and adding the integer l (|l| <= 2^41) is exact too.  |mul| <= p/2 + 1.5|a|p/2^53.
+//   forward (Cooley-Tukey) stage: values grow by at most |mul| ~ p/2 per stage: <= 6.1p after 11
+//     stages; inverse (Gentleman-Sande) stage: sums double: p/2 -> 2^11 * p/2 = 2^52 for N = 2048.
+//     Every add/sub result stays below 2^53, hence exact.  Accumulators (sum of R products, each
+//     <= 0.51p) are reduced to |.| <= p/2 before the inverse transform.
+//   lift: the true integer result t of one part satisfies |t| <= R*N*B*2^15 < p/2 (checked when the
+//     context is created), so the balanced residue IS t.
+// The 32-bit key word is split into two signed 16-bit halves w = lo + 2^16 hi (two spectra per key
+// polynomial, two accumulators per output column); result = t_lo + 2^16 t_hi mod 2^32.
+#pragma once
+#include <math.h>
+
+#include "platform.h"
+
+namespace tfhe {
+
+struct FpField {
+  typedef double elem;
+  static constexpr int kParts = 2;
+  static constexpr int kId = 2;
+
+  static constexpr double P = 4398046486529.0;  // 2^42 - 24575
+  static constexpr double PINV = 1.0 / 4398046486529.0;
+  static constexpr u64 P_INT = 4398046486529ull;
+  static constexpr u64 ROOT_8192 = 0;  // unused; see root_of_unity()
+
+  TFHE_HD static elem zero() { return 0.0; }
+  TFHE_HD static elem add(elem a, elem b) { return a + b; }
+  TFHE_HD static elem sub(elem a, elem b) { return a - b; }
+  TFHE_HD static elem mul(elem a, elem w) {
+    const double h = a * w;
+    const double l = __builtin_fma(a, w, -h);
+    const double q = __builtin_rint(h * PINV);
+    return __builtin_fma(-q, P, h) + l;
+  }
+  // x -> balanced residue, |x| < 2^53
+  TFHE_HD static elem reduce(elem x) { return __builtin_fma(-__builtin_rint(x * PINV), P, x); }
+  TFHE_HD static elem from_digit(u32 d) { return (double)(i32)d; }
+  // signed 16-bit halves of the key word taken as a signed 32-bit integer
+  TFHE_HD static elem from_key_word(u32 w, int part) {
+    const i32 lo = (i32)(int16_t)(w & 0xFFFFu);
+    if (part == 0) return (double)lo;
+    return (double)(((i32)w - lo) >> 16);  // exact: the difference is a multiple of 2^16
+  }
+  TFHE_HD static elem before_inverse(elem a) { return reduce(a); }
+  // exact integer t (|t| < 2^52) -> t mod 2^32
+  TFHE_HD static u32 to_u32(elem t) {
+    const double f = __builtin_floor(t * (1.0 / 4294967296.0));
+    return (u32)__builtin_fma(-4294967296.0, f, t);
+  }
+  TFHE_HD static u32 finish(const elem (&parts)[kParts]) {
+    return to_u32(reduce(parts[0])) + (to_u32(reduce(parts[1])) << 16);
+  }
+
+  // ---- host-side constants (integer arithmetic mod p) ----
+  static inline u64 mulmod_u64(u64 a, u64 b) { return (u64)((unsigned __int128)a * b % P_INT); }
+  static inline u64 powmod_u64(u64 b, u64 e) {
+    u64 r = 1;
+    while (e) {
+      if (e & 1) r = mulmod_u64(r, b);
+      b = mulmod_u64(b, b);
+      e >>= 1;
+    }
+    return r;
+  }
+  static inline double balanced(u64 v) { return v > P_INT / 2 ? -(double)(P_INT - v) : (double)v; }
+  static inline void fill_twiddles(int logn, elem* out) {
+    const int n = 1 << logn;
+    const u64 psi = powmod_u64(3, (P_INT - 1) >> (logn + 1));  // 3 generates F_p^*
+    u64 pw = 1;
+    for (int k = 0; k < n; ++k) {
+      int rev = 0;
+      for (int b = 0; b < logn; ++b) rev |= ((k >> b) & 1) << (logn - 1 - b);
+      out[rev] = balanced(pw);
+      pw = mulmod_u64(pw, psi);
+    }
+  }
+  static inline elem n_inv(int logn) { return balanced(powmod_u64((u64)1 << logn, P_INT - 2)); }
+  static inline double exact_bits() { return 40.9; }  // |t| < p/2 = 2^41 with margin
+  static inline double key_bits() { return 15.0; }    // each half is <= 2^15 in magnitude
+};
+
+}  // namespace tfhe

@@ -1,0 +1,45 @@
+// field_gl.h -- field policy: Goldilocks prime p = 2^64 - 2^32 + 1, elements u64 (goldilocks.h).
+// One spectrum per key polynomial.  Exact for every parameter set with R*N*B*2^32 < 2^62.
+#pragma once
+#include "goldilocks.h"
+
+namespace tfhe {
+
+struct GlField {
+  typedef u64 elem;
+  static constexpr int kParts = 1;  // spectra per bootstrapping-key polynomial
+  static constexpr int kId = 1;
+
+  TFHE_HD static elem zero() { return 0; }
+  TFHE_HD static elem add(elem a, elem b) { return gl::add(a, b); }
+  TFHE_HD static elem sub(elem a, elem b) { return gl::sub(a, b); }
+  TFHE_HD static elem mul(elem a, elem w) { return gl::mul(a, w); }
+  // gadget digit (wrapped u32 holding a small signed integer) -> field element
+  TFHE_HD static elem from_digit(u32 d) { return gl::from_i32(d); }
+  // key word -> field element of spectrum `part`
+  TFHE_HD static elem from_key_word(u32 w, int /*part*/) { return (elem)w; }
+  // called on every accumulator before the inverse transform
+  TFHE_HD static elem before_inverse(elem a) { return a; }
+  // inverse-transform outputs of all parts -> value mod 2^32
+  TFHE_HD static u32 finish(const elem (&parts)[kParts]) { return gl::lift_mod_2_32(parts[0]); }
+
+  // ---- host-side constants ----
+  static inline void fill_twiddles(int logn, elem* out) {
+    const int n = 1 << logn;
+    const u64 psi = gl::root_of_unity(logn + 1);
+    u64 pw = 1;
+    for (int k = 0; k < n; ++k) {
+      int rev = 0;
+      for (int b = 0; b < logn; ++b) rev |= ((k >> b) & 1) << (logn - 1 - b);
+      out[rev] = pw;  // psi_rev[j] = psi^bitrev(j)
+      pw = gl::mul(pw, psi);
+    }
+  }
+  static inline elem n_inv(int logn) { return gl::inv((u64)1 << logn); }
+  // log2 of the largest |integer convolution value| this field lifts exactly
+  static inline double exact_bits() { return 62.0; }
+  // log2 of the magnitude of one key operand as seen by the convolution
+  static inline double key_bits() { return 32.0; }
+};
+
+}  // namespace tfhe

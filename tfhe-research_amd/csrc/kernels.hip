@@ -1,21 +1,23 @@
 // kernels.hip -- gfx950 (CDNA4 / MI355X) kernels of the TFHE bootstrapping hot path.
 //
-// Execution shape: ONE 64-lane wavefront per LWE sample / per polynomial (pbs_wave.h).  A
-// workgroup is just a bundle of independent waves that share the twiddle table in LDS; after
-// the table is staged there is no workgroup barrier anywhere, only wave-local LDS ordering.
-//
-// LDS layout of a per-wave kernel (dynamic, base 16-B aligned, no static LDS in front of it):
-//   [ twiddles psi_rev : N u64 ][ wave 0: scratch N u64 | acc (K+1)*N u32 ][ wave 1: ... ] ...
+// Execution shape: one workgroup = one TEAM of K+1 wavefronts = one LWE sample; wave c owns GLWE
+// polynomial c and output column c (pbs_wave.h).  Transforms are wave-local (no barrier); the
+// team meets at a workgroup barrier twice per gadget level to exchange digit spectra through LDS.
 #include "launch.h"
 
 namespace tfhe {
 namespace {
 
+template <class Elem>
 struct DeviceWave {
-  u64* scratch_;
+  unsigned char* team_base_;  // LDS of wave 0 of this team
+  Elem* scratch_;
   u32* acc_;
-  const u64* tw_;
+  const Elem* tw_;
+  int wave_;
+  unsigned wave_stride_;      // bytes of LDS per wave
   __device__ __forceinline__ int lane() const { return (int)(threadIdx.x & 63u); }
+  __device__ __forceinline__ int wave() const { return wave_; }
   // Orders this wave's LDS stores before its later LDS loads.  All 64 lanes run in lockstep and
   // the LDS pipeline is in-order per wave, so only the compiler has to be fenced.
   __device__ __forceinline__ void sync() const {
@@ -23,33 +25,58 @@ struct DeviceWave {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
-  __device__ __forceinline__ u64* scratch() const { return scratch_; }
+  // workgroup barrier: the team of K+1 waves that shares one sample IS the workgroup
+  __device__ __forceinline__ void team_sync() const { __syncthreads(); }
+  __device__ __forceinline__ Elem* scratch() const { return scratch_; }
+  __device__ __forceinline__ const Elem* scratch_of(int s) const {
+    return reinterpret_cast<const Elem*>(team_base_ + (size_t)s * wave_stride_);
+  }
   __device__ __forceinline__ u32* acc() const { return acc_; }
-  __device__ __forceinline__ const u64* twiddles() const { return tw_; }
+  __device__ __forceinline__ const Elem* twiddles() const { return tw_; }
   __device__ __forceinline__ u32 uniform(u32 v) const { return __builtin_amdgcn_readfirstlane(v); }
+  // keeps a value (the xor of the cache-line touch loads) alive without any instruction
+  __device__ __forceinline__ void keep(u32 v) const { asm volatile("" ::"v"(v)); }
+  // compiler-only barrier: memory operations are not moved across it
+  __device__ __forceinline__ void compiler_fence() const { asm volatile("" ::: "memory"); }
 };
 
+#ifndef TFHE_WAVES_PER_SIMD_GL
+#define TFHE_WAVES_PER_SIMD_GL 3
+#endif
+#ifndef TFHE_WAVES_PER_SIMD_FP
+#define TFHE_WAVES_PER_SIMD_FP 3
+#endif
+
+// One workgroup = one team = K+1 waves = one LWE sample.
+// LDS (dynamic, 16-B aligned base, no static LDS): [ twiddles N x 8 B ][ wave w: transpose/exchange
+// buffer N x 8 B | accumulator polynomial N x 4 B ] for w = 0..K
 template <int LOGN, int K>
-struct WaveCfg {
+struct TeamCfg {
   static constexpr int N = 1 << LOGN;
-  // waves per workgroup: bounded by 160 KiB LDS per CU and the register budget
-  static constexpr int kWaves = (LOGN == 11) ? 2 : 4;
-  static constexpr int kMinWavesPerSimd = (LOGN == 11) ? 1 : 2;
-  static constexpr size_t kWaveLds = (size_t)N * 8 + (size_t)(K + 1) * N * 4;
-  static constexpr size_t kLds = (size_t)N * 8 + kWaves * kWaveLds;
+  static constexpr int kWaves = K + 1;
+  static constexpr int kThreads = kWaves * 64;
+  static constexpr unsigned kWaveLds = (unsigned)N * 8u + (unsigned)N * 4u;
+  static constexpr size_t kLds = (size_t)N * 8 + (size_t)kWaves * kWaveLds;
+  // register budget: E = N/64 elements per array per lane
+  static constexpr int kMinWavesGl = (LOGN == 11) ? 2 : TFHE_WAVES_PER_SIMD_GL;
+  static constexpr int kMinWavesFp = (LOGN == 11) ? 2 : TFHE_WAVES_PER_SIMD_FP;
 };
 
-template <int LOGN, int K>
-__device__ __forceinline__ DeviceWave make_wave(unsigned char* smem, const u64* tw_global) {
-  using C = WaveCfg<LOGN, K>;
-  u64* tw = reinterpret_cast<u64*>(smem);
+template <class F, int LOGN, int K>
+__device__ __forceinline__ DeviceWave<typename F::elem> make_wave(unsigned char* smem,
+                                                                   const typename F::elem* tw_global) {
+  typedef typename F::elem elem;
+  using C = TeamCfg<LOGN, K>;
+  elem* tw = reinterpret_cast<elem*>(smem);
   for (int i = threadIdx.x; i < C::N; i += blockDim.x) tw[i] = tw_global[i];
   __syncthreads();
-  const int wave = (int)(threadIdx.x >> 6);
-  unsigned char* base = smem + (size_t)C::N * 8 + (size_t)wave * C::kWaveLds;
-  DeviceWave w;
+  DeviceWave<elem> w;
+  w.wave_ = (int)(threadIdx.x >> 6);
+  w.wave_stride_ = C::kWaveLds;
+  w.team_base_ = smem + (size_t)C::N * 8;
+  unsigned char* base = w.team_base_ + (size_t)w.wave_ * C::kWaveLds;
   w.tw_ = tw;
-  w.scratch_ = reinterpret_cast<u64*>(base);
+  w.scratch_ = reinterpret_cast<elem*>(base);
   w.acc_ = reinterpret_cast<u32*>(base + (size_t)C::N * 8);
   return w;
 }
@@ -57,83 +84,89 @@ __device__ __forceinline__ DeviceWave make_wave(unsigned char* smem, const u64* 
 extern __shared__ __attribute__((aligned(16))) unsigned char g_smem[];
 
 // ------------------------------------------------------------------------------ bsk_prepare
-template <int LOGN>
-__global__ void __launch_bounds__(256) bsk_prepare_kernel(const u64* __restrict__ tw,
+template <class F, int LOGN>
+__global__ void __launch_bounds__(256) bsk_prepare_kernel(const typename F::elem* __restrict__ tw,
                                                          const u32* __restrict__ polys,
-                                                         size_t poly_count, u64* __restrict__ spectra,
-                                                         u64 n_inv) {
+                                                         size_t poly_count,
+                                                         typename F::elem* __restrict__ spectra,
+                                                         typename F::elem n_inv) {
+  typedef typename F::elem elem;
   constexpr int N = 1 << LOGN;
-  u64* twl = reinterpret_cast<u64*>(g_smem);
+  elem* twl = reinterpret_cast<elem*>(g_smem);
   for (int i = threadIdx.x; i < N; i += blockDim.x) twl[i] = tw[i];
   __syncthreads();
   const int wave = (int)(threadIdx.x >> 6);
   const size_t poly = (size_t)blockIdx.x * (blockDim.x >> 6) + wave;
   if (poly >= poly_count) return;
-  DeviceWave w;
+  DeviceWave<elem> w;
+  w.wave_ = 0;
+  w.wave_stride_ = 0;
+  w.team_base_ = nullptr;
   w.tw_ = twl;
-  w.scratch_ = reinterpret_cast<u64*>(g_smem + (size_t)N * 8 + (size_t)wave * N * 8);
+  w.scratch_ = reinterpret_cast<elem*>(g_smem + (size_t)N * 8 + (size_t)wave * N * 8);
   w.acc_ = nullptr;
-  bsk_prepare_wave<LOGN>(w, polys + poly * N, spectra + poly * N, n_inv);
+  bsk_prepare_wave<F, LOGN>(w, polys + poly * N, spectra + poly * N * F::kParts, n_inv);
 }
 
 // ------------------------------------------------------------------------------ blind rotation
-template <int LOGN, int K>
-__global__ void __launch_bounds__((WaveCfg<LOGN, K>::kWaves * 64), (WaveCfg<LOGN, K>::kMinWavesPerSimd))
-blind_rotate_kernel(PbsParams P, const u64* __restrict__ tw, const u32* __restrict__ lwe_in,
-                    size_t batch, const u32* __restrict__ tv, size_t tv_stride,
-                    const u64* __restrict__ bsk, u32* __restrict__ glwe_out,
-                    u32* __restrict__ lwe_extracted) {
-  using C = WaveCfg<LOGN, K>;
+template <class F, int LOGN, int K>
+__global__ void __launch_bounds__((TeamCfg<LOGN, K>::kThreads),
+                                  (F::kParts == 2 ? TeamCfg<LOGN, K>::kMinWavesFp
+                                                  : TeamCfg<LOGN, K>::kMinWavesGl))
+blind_rotate_kernel(PbsParams P, const typename F::elem* __restrict__ tw,
+                    const u32* __restrict__ lwe_in, size_t batch, const u32* __restrict__ tv,
+                    size_t tv_stride, const typename F::elem* __restrict__ bsk,
+                    u32* __restrict__ glwe_out, u32* __restrict__ lwe_extracted) {
+  using C = TeamCfg<LOGN, K>;
   constexpr int N = C::N;
   constexpr int E = NttShape<LOGN>::kE;
-  DeviceWave w = make_wave<LOGN, K>(g_smem, tw);
-  const size_t sample = (size_t)blockIdx.x * C::kWaves + (threadIdx.x >> 6);
-  if (sample >= batch) return;
+  auto w = make_wave<F, LOGN, K>(g_smem, tw);
+  const size_t sample = blockIdx.x;  // grid = batch: no ragged tail, every wave runs every barrier
 
-  blind_rotate_wave<LOGN, K>(w, P, lwe_in + sample * (P.n + 1), tv + sample * tv_stride, bsk);
+  blind_rotate_team<F, LOGN, K>(w, P, lwe_in + sample * (P.n + 1), tv + sample * tv_stride, bsk);
 
   const int lane = w.lane();
   if (glwe_out) {
-    u32* dst = glwe_out + sample * (size_t)(K + 1) * N;
+    u32* dst = glwe_out + (sample * (size_t)(K + 1) + w.wave()) * N;
 #pragma unroll
-    for (int p = 0; p <= K; ++p)
-#pragma unroll
-      for (int r = 0; r < E; ++r) dst[p * N + r * 64 + lane] = w.acc()[p * N + r * 64 + lane];
+    for (int r = 0; r < E; ++r) dst[r * 64 + lane] = w.acc()[r * 64 + lane];
   }
-  if (lwe_extracted) sample_extract_wave<LOGN, K>(w, lwe_extracted + sample * ((size_t)K * N + 1));
+  if (lwe_extracted) sample_extract_team<LOGN, K>(w, lwe_extracted + sample * ((size_t)K * N + 1));
 }
 
 // ------------------------------------------------------------------------------ external product
-template <int LOGN, int K>
-__global__ void __launch_bounds__((WaveCfg<LOGN, K>::kWaves * 64), (WaveCfg<LOGN, K>::kMinWavesPerSimd))
-external_product_kernel(PbsParams P, const u64* __restrict__ tw, const u64* __restrict__ ggsw,
-                        size_t ggsw_stride_words, const u32* glwe_in, u32* ct1_inout,
-                        const u32* cmux_ct0, size_t batch, u32* glwe_out) {
-  using C = WaveCfg<LOGN, K>;
+template <class F, int LOGN, int K>
+__global__ void __launch_bounds__((TeamCfg<LOGN, K>::kThreads),
+                                  (F::kParts == 2 ? TeamCfg<LOGN, K>::kMinWavesFp
+                                                  : TeamCfg<LOGN, K>::kMinWavesGl))
+external_product_kernel(PbsParams P, const typename F::elem* __restrict__ tw,
+                        const typename F::elem* __restrict__ ggsw, size_t ggsw_stride_words,
+                        const u32* glwe_in, u32* ct1_inout, const u32* cmux_ct0, size_t batch,
+                        u32* glwe_out) {
+  using C = TeamCfg<LOGN, K>;
   constexpr int N = C::N;
-  DeviceWave w = make_wave<LOGN, K>(g_smem, tw);
-  const size_t sample = (size_t)blockIdx.x * C::kWaves + (threadIdx.x >> 6);
-  if (sample >= batch) return;
-  const size_t ct = sample * (size_t)(K + 1) * N;
-  const u64* g = ggsw + sample * ggsw_stride_words;
-  u32* dst = glwe_out + ct;
+  auto w = make_wave<F, LOGN, K>(g_smem, tw);
+  const size_t sample = blockIdx.x;
+  const size_t poly = (sample * (size_t)(K + 1) + w.wave()) * N;  // my polynomial / my output column
+  const typename F::elem* g = ggsw + sample * ggsw_stride_words;
+  u32* dst = glwe_out + poly;
   if (cmux_ct0 == nullptr) {
-    const u32* in = glwe_in + ct;
-    auto src = [&](int p, int j) -> u32 { return in[p * N + j]; };
-    auto out = [&](int p, int j, u32 v) { dst[p * N + j] = v; };
-    external_product_wave<LOGN, K>(w, P, g, src, out);
+    const u32* in = glwe_in + poly;
+    auto src = [&](int j) -> u32 { return in[j]; };
+    auto out = [&](int j, u32 v) { dst[j] = v; };
+    external_product_team<F, LOGN, K>(w, P, g, src, out);
   } else {
-    const u32* c0 = cmux_ct0 + ct;
-    u32* c1 = ct1_inout + ct;
+    const u32* c0 = cmux_ct0 + poly;
+    u32* c1 = ct1_inout + poly;
     // *glwe_ciphertext1 -= glwe_ciphertext0 (ggsw.rs:171): each coefficient is read and written
     // by the one lane that owns index j, so the in-place update is race free
-    auto src = [&](int p, int j) -> u32 {
-      const u32 d = c1[p * N + j] - c0[p * N + j];
-      c1[p * N + j] = d;
+    auto src = [&](int j) -> u32 {
+      const u32 d = c1[j] - c0[j];
+      c1[j] = d;
       return d;
     };
-    auto out = [&](int p, int j, u32 v) { dst[p * N + j] = v + c0[p * N + j]; };
-    external_product_wave<LOGN, K>(w, P, g, src, out);
+    auto out = [&](int j, u32 v) { dst[j] = v + c0[j]; };
+    external_product_team<F, LOGN, K>(w, P, g, src, out);
   }
 }
 
@@ -308,46 +341,50 @@ hipError_t allow_lds(Kern kern, size_t bytes) {
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-template <int LOGN, int K>
-hipError_t launch_blind_rotate(hipStream_t s, const PbsParams& P, const u64* tw, const u32* lwe_in,
-                               size_t batch, const u32* tv, size_t tv_stride, const u64* bsk,
+template <class F, int LOGN, int K>
+hipError_t launch_blind_rotate(hipStream_t s, const PbsParams& P, const void* tw_v, const u32* lwe_in,
+                               size_t batch, const u32* tv, size_t tv_stride, const void* bsk_v,
                                u32* glwe_out, u32* lwe_extracted) {
-  using C = WaveCfg<LOGN, K>;
-  auto kern = blind_rotate_kernel<LOGN, K>;
+  using C = TeamCfg<LOGN, K>;
+  auto tw = static_cast<const typename F::elem*>(tw_v);
+  auto bsk = static_cast<const typename F::elem*>(bsk_v);
+  auto kern = blind_rotate_kernel<F, LOGN, K>;
   hipError_t e = allow_lds(kern, C::kLds);
   if (e != hipSuccess) return e;
-  const unsigned grid = (unsigned)((batch + C::kWaves - 1) / C::kWaves);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(C::kWaves * 64), C::kLds, s, P, tw, lwe_in, batch, tv,
-                     tv_stride, bsk, glwe_out, lwe_extracted);
+  hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(C::kThreads), C::kLds, s, P, tw, lwe_in, batch,
+                     tv, tv_stride, bsk, glwe_out, lwe_extracted);
   return hipGetLastError();
 }
 
-template <int LOGN, int K>
-hipError_t launch_external_product(hipStream_t s, const PbsParams& P, const u64* tw, const u64* ggsw,
-                                   size_t ggsw_stride_words, const u32* glwe_in, u32* ct1_inout,
-                                   const u32* cmux_ct0, size_t batch, u32* glwe_out) {
-  using C = WaveCfg<LOGN, K>;
-  auto kern = external_product_kernel<LOGN, K>;
+template <class F, int LOGN, int K>
+hipError_t launch_external_product(hipStream_t s, const PbsParams& P, const void* tw_v,
+                                   const void* ggsw_v, size_t ggsw_stride_words, const u32* glwe_in,
+                                   u32* ct1_inout, const u32* cmux_ct0, size_t batch, u32* glwe_out) {
+  using C = TeamCfg<LOGN, K>;
+  auto tw = static_cast<const typename F::elem*>(tw_v);
+  auto ggsw = static_cast<const typename F::elem*>(ggsw_v);
+  auto kern = external_product_kernel<F, LOGN, K>;
   hipError_t e = allow_lds(kern, C::kLds);
   if (e != hipSuccess) return e;
-  const unsigned grid = (unsigned)((batch + C::kWaves - 1) / C::kWaves);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(C::kWaves * 64), C::kLds, s, P, tw, ggsw,
+  hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(C::kThreads), C::kLds, s, P, tw, ggsw,
                      ggsw_stride_words, glwe_in, ct1_inout, cmux_ct0, batch, glwe_out);
   return hipGetLastError();
 }
 
-template <int LOGN>
-hipError_t launch_bsk_prepare(hipStream_t s, const u64* tw, const u32* polys, size_t poly_count,
-                              u64* spectra) {
+template <class F, int LOGN>
+hipError_t launch_bsk_prepare(hipStream_t s, const void* tw_v, const u32* polys, size_t poly_count,
+                              void* spectra_v) {
   constexpr int N = 1 << LOGN;
   constexpr int waves = 4;
   const size_t lds = (size_t)N * 8 * (1 + waves);
-  auto kern = bsk_prepare_kernel<LOGN>;
+  auto tw = static_cast<const typename F::elem*>(tw_v);
+  auto spectra = static_cast<typename F::elem*>(spectra_v);
+  auto kern = bsk_prepare_kernel<F, LOGN>;
   hipError_t e = allow_lds(kern, lds);
   if (e != hipSuccess) return e;
   const unsigned grid = (unsigned)((poly_count + waves - 1) / waves);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(waves * 64), lds, s, tw, polys, poly_count, spectra,
-                     gl::inv((u64)N));
+                     F::n_inv(LOGN));
   return hipGetLastError();
 }
 
@@ -357,66 +394,83 @@ namespace launch {
 
 bool shape_supported(u32 log_n, u32 k) { return log_n >= 9 && log_n <= 11 && (k == 1 || k == 2); }
 
-int waves_per_block(u32 log_n, u32 /*k*/) { return log_n == 11 ? 2 : 4; }
+int waves_per_block(u32 /*log_n*/, u32 k) { return (int)k + 1; }
 
+int field_parts(int field) { return field == kFieldFp64 ? FpField::kParts : GlField::kParts; }
+
+// (field, log_n, k) -> template instantiation.  TFHE_DEV_CFG2_ONLY builds just the BASELINE cfg2
+// shape (N = 1024, k = 1) for fast iteration on the kernels.
 #if defined(TFHE_DEV_CFG2_ONLY)
-#define TFHE_DISPATCH_SHAPE(log_n, k, CALL)                                   \
-  do {                                                                        \
-    if ((k) == 1 && (log_n) == 10) {                                          \
-      constexpr int KK = 1;                                                   \
-      constexpr int LL = 10;                                                  \
-      return CALL;                                                            \
-    }                                                                         \
-    return hipErrorInvalidValue;                                              \
-  } while (0)
+#define TFHE_DISPATCH_LOGN_K(log_n, k, CALL)                                  \
+  if ((k) == 1 && (log_n) == 10) {                                            \
+    constexpr int KK = 1;                                                     \
+    constexpr int LL = 10;                                                    \
+    return CALL;                                                              \
+  }
+#define TFHE_DISPATCH_LOGN(log_n, CALL)                                       \
+  if ((log_n) == 10) {                                                        \
+    constexpr int LL = 10;                                                    \
+    return CALL;                                                              \
+  }
 #else
-#define TFHE_DISPATCH_SHAPE(log_n, k, CALL)                                   \
-  do {                                                                        \
-    if ((k) == 1) {                                                           \
-      constexpr int KK = 1;                                                   \
-      switch (log_n) {                                                        \
-        case 9: { constexpr int LL = 9; return CALL; }                        \
-        case 10: { constexpr int LL = 10; return CALL; }                      \
-        case 11: { constexpr int LL = 11; return CALL; }                      \
-        default: break;                                                       \
-      }                                                                       \
-    } else if ((k) == 2) {                                                    \
-      constexpr int KK = 2;                                                   \
-      switch (log_n) {                                                        \
-        case 9: { constexpr int LL = 9; return CALL; }                        \
-        case 10: { constexpr int LL = 10; return CALL; }                      \
-        case 11: { constexpr int LL = 11; return CALL; }                      \
-        default: break;                                                       \
-      }                                                                       \
+#define TFHE_DISPATCH_LOGN_K(log_n, k, CALL)                                  \
+  if ((k) == 1) {                                                             \
+    constexpr int KK = 1;                                                     \
+    switch (log_n) {                                                          \
+      case 9: { constexpr int LL = 9; return CALL; }                          \
+      case 10: { constexpr int LL = 10; return CALL; }                        \
+      case 11: { constexpr int LL = 11; return CALL; }                        \
+      default: break;                                                         \
     }                                                                         \
-    return hipErrorInvalidValue;                                              \
-  } while (0)
+  } else if ((k) == 2) {                                                      \
+    constexpr int KK = 2;                                                     \
+    switch (log_n) {                                                          \
+      case 9: { constexpr int LL = 9; return CALL; }                          \
+      case 10: { constexpr int LL = 10; return CALL; }                        \
+      case 11: { constexpr int LL = 11; return CALL; }                        \
+      default: break;                                                         \
+    }                                                                         \
+  }
+#define TFHE_DISPATCH_LOGN(log_n, CALL)                                       \
+  switch (log_n) {                                                            \
+    case 9: { constexpr int LL = 9; return CALL; }                            \
+    case 10: { constexpr int LL = 10; return CALL; }                          \
+    case 11: { constexpr int LL = 11; return CALL; }                          \
+    default: break;                                                           \
+  }
 #endif
 
-hipError_t bsk_prepare(hipStream_t s, u32 log_n, const u64* tw, const u32* polys, size_t poly_count,
-                       u64* spectra) {
-  switch (log_n) {
-    case 9: return launch_bsk_prepare<9>(s, tw, polys, poly_count, spectra);
-    case 10: return launch_bsk_prepare<10>(s, tw, polys, poly_count, spectra);
-    case 11: return launch_bsk_prepare<11>(s, tw, polys, poly_count, spectra);
-    default: return hipErrorInvalidValue;
-  }
+#define TFHE_DISPATCH_FIELD(field, BODY)                                      \
+  do {                                                                        \
+    if ((field) == kFieldGoldilocks) {                                        \
+      typedef GlField FF;                                                     \
+      BODY                                                                    \
+    } else if ((field) == kFieldFp64) {                                       \
+      typedef FpField FF;                                                     \
+      BODY                                                                    \
+    }                                                                         \
+    return hipErrorInvalidValue;                                              \
+  } while (0)
+
+hipError_t bsk_prepare(hipStream_t s, int field, u32 log_n, const void* tw, const u32* polys,
+                       size_t poly_count, void* spectra) {
+  TFHE_DISPATCH_FIELD(field, TFHE_DISPATCH_LOGN(log_n, (launch_bsk_prepare<FF, LL>(s, tw, polys, poly_count, spectra))));
 }
 
-hipError_t blind_rotate(hipStream_t s, const PbsParams& P, const u64* tw, const u32* lwe_in,
-                        size_t batch, const u32* tv, size_t tv_stride, const u64* bsk,
-                        u32* glwe_out, u32* lwe_extracted) {
-  TFHE_DISPATCH_SHAPE(P.log_n, P.k,
-                      (launch_blind_rotate<LL, KK>(s, P, tw, lwe_in, batch, tv, tv_stride, bsk,
-                                                   glwe_out, lwe_extracted)));
+hipError_t blind_rotate(hipStream_t s, int field, const PbsParams& P, const void* tw,
+                        const u32* lwe_in, size_t batch, const u32* tv, size_t tv_stride,
+                        const void* bsk, u32* glwe_out, u32* lwe_extracted) {
+  TFHE_DISPATCH_FIELD(field, TFHE_DISPATCH_LOGN_K(P.log_n, P.k,
+                      (launch_blind_rotate<FF, LL, KK>(s, P, tw, lwe_in, batch, tv, tv_stride, bsk,
+                                                       glwe_out, lwe_extracted))));
 }
 
-hipError_t external_product(hipStream_t s, const PbsParams& P, const u64* tw, const u64* ggsw,
-                            size_t ggsw_stride_words, const u32* glwe_in, u32* ct1_inout,
-                            const u32* cmux_ct0, size_t batch, u32* glwe_out) {
-  TFHE_DISPATCH_SHAPE(P.log_n, P.k,
-                      (launch_external_product<LL, KK>(s, P, tw, ggsw, ggsw_stride_words, glwe_in,
-                                                       ct1_inout, cmux_ct0, batch, glwe_out)));
+hipError_t external_product(hipStream_t s, int field, const PbsParams& P, const void* tw,
+                            const void* ggsw, size_t ggsw_stride_words, const u32* glwe_in,
+                            u32* ct1_inout, const u32* cmux_ct0, size_t batch, u32* glwe_out) {
+  TFHE_DISPATCH_FIELD(field, TFHE_DISPATCH_LOGN_K(P.log_n, P.k,
+                      (launch_external_product<FF, LL, KK>(s, P, tw, ggsw, ggsw_stride_words, glwe_in,
+                                                           ct1_inout, cmux_ct0, batch, glwe_out))));
 }
 
 hipError_t key_switch(hipStream_t s, const KsParams& K, u32 big_n, u32 n, const u32* lwe_in,

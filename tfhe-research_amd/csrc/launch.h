@@ -7,28 +7,35 @@
 namespace tfhe {
 namespace launch {
 
+// NTT backends (field policies): values of the `field` argument below
+constexpr int kFieldGoldilocks = GlField::kId;  // 1
+constexpr int kFieldFp64 = FpField::kId;        // 2
+
 // true if a kernel set is instantiated for (log_n, k)
 bool shape_supported(u32 log_n, u32 k);
+// spectra per key polynomial for a field (1 or 2)
+int field_parts(int field);
 // waves (= samples) per workgroup used by the per-wave kernels for this shape
 int waves_per_block(u32 log_n, u32 k);
 
-// twiddle table psi_rev[N] (u64) must already be on the device
-hipError_t bsk_prepare(hipStream_t s, u32 log_n, const u64* tw, const u32* polys, size_t poly_count,
-                       u64* spectra);
+// twiddle table psi_rev[N] (8-byte field elements) must already be on the device;
+// spectra: poly_count x field_parts x N elements
+hipError_t bsk_prepare(hipStream_t s, int field, u32 log_n, const void* tw, const u32* polys,
+                       size_t poly_count, void* spectra);
 
 // Blind rotation of `batch` samples.  Optional outputs: glwe_out [batch][k+1][N] and/or
 // lwe_extracted [batch][k*N+1] (sample extract at index 0 fused in).
-hipError_t blind_rotate(hipStream_t s, const PbsParams& P, const u64* tw, const u32* lwe_in,
-                        size_t batch, const u32* tv, size_t tv_stride, const u64* bsk,
-                        u32* glwe_out, u32* lwe_extracted);
+hipError_t blind_rotate(hipStream_t s, int field, const PbsParams& P, const void* tw,
+                        const u32* lwe_in, size_t batch, const u32* tv, size_t tv_stride,
+                        const void* bsk, u32* glwe_out, u32* lwe_extracted);
 
 // out = external_product(ggsw[g], glwe[b]) (+ ct0 for the CMUX form).
 //   cmux_ct0 == nullptr : src = glwe_in
 //   cmux_ct0 != nullptr : src = ct1 - ct0 where ct1 = glwe_inout_ct1 (overwritten with the
 //                         difference, ggsw.rs:171), out = product + ct0
-hipError_t external_product(hipStream_t s, const PbsParams& P, const u64* tw, const u64* ggsw,
-                            size_t ggsw_stride_words, const u32* glwe_in, u32* ct1_inout,
-                            const u32* cmux_ct0, size_t batch, u32* glwe_out);
+hipError_t external_product(hipStream_t s, int field, const PbsParams& P, const void* tw,
+                            const void* ggsw, size_t ggsw_stride_words, const u32* glwe_in,
+                            u32* ct1_inout, const u32* cmux_ct0, size_t batch, u32* glwe_out);
 
 // key_switch_lwe over a batch: lwe_in [batch][big_n+1], ksk [big_n*levels][n+1], out [batch][n+1]
 hipError_t key_switch(hipStream_t s, const KsParams& K, u32 big_n, u32 n, const u32* lwe_in,

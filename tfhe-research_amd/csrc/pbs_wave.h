@@ -1,9 +1,9 @@
 // pbs_wave.h -- per-wavefront bodies of the bootstrapping hot path (host/device source).
 //
-// One 64-lane wavefront owns one LWE sample for the whole blind rotation: the GLWE accumulator
-// stays in wave-private LDS for all n CMUX iterations, nothing is exchanged with other waves, and
-// the only global traffic inside the loop is the (batch-shared, L2/Infinity-Cache resident)
-// NTT-domain bootstrapping key.  The same bodies are compiled by g++ for the SIMT emulator that
+// A team of K+1 wavefronts (one workgroup) owns one LWE sample for the whole blind rotation: wave c
+// keeps polynomial c of the GLWE accumulator in its private LDS for all n CMUX iterations, the
+// waves exchange only digit spectra through LDS, and the only global traffic inside the loop is the
+// (batch-shared, L2/Infinity-Cache resident) NTT-domain bootstrapping key.  The same bodies are compiled by g++ for the SIMT emulator that
 // the CPU tests use (tests/emu), so what is parity-tested on the CPU is the code that runs on the
 // GPU.
 //
@@ -88,78 +88,145 @@ TFHE_HD u32 monomial_coeff(const u32* poly, int j, u32 m) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// GGSW (NTT domain) x GLWE external product, accumulated in the NTT domain.
-//   src(p, j)  -> coefficient j of polynomial p of the GLWE operand (a functor, lane-local)
-//   ggsw       -> prepared GGSW: [R][K+1] spectra of N u64 in spectrum_slot order, pre-scaled by
-//                 N^-1 (so the unscaled inverse NTT below lands on the true product)
-//   out(p, j, value mod 2^32) is called once per output coefficient.
+// GGSW (NTT domain) x GLWE external product by a TEAM of K+1 wavefronts (one workgroup).
+//
+// Wave c (c = ctx.wave(), 0..K) owns GLWE polynomial c on the input side and output column c:
+//   - it decomposes polynomial c and forward-transforms its `levels` digit rows,
+//   - publishes each spectrum in its LDS transpose buffer (free between two transforms),
+//   - after a workgroup barrier every wave multiplies ALL K+1 published spectra of that level with
+//     the key spectra of ITS column and accumulates in registers (F::kParts accumulators of E
+//     elements -- independent of K),
+//   - finally inverse-transforms its own column.
+// So a wave does levels forward + kParts inverse transforms and (K+1)*levels*kParts MAC tiles, the
+// accumulators are (K+1)x smaller than with one wave per sample, and nothing but spectra crosses
+// waves.  Two workgroup barriers per level (publish -> consume -> reuse of the buffer).
+//
+//   src(j)  -> coefficient j of polynomial c of the GLWE operand (functor, lane-local)
+//   ggsw    -> prepared GGSW: [R][K+1][F::kParts] spectra of N elements in spectrum_slot order,
+//              pre-scaled by N^-1 (so the unscaled inverse NTT lands on the true product)
+//   out(j, value mod 2^32) is called once per coefficient of output polynomial c.
+// Every wave of the team must call this the same number of times (it contains barriers).
 // ---------------------------------------------------------------------------------------------
-template <int LOGN, int K, class Ctx, class Src, class Out>
-TFHE_HD void external_product_wave(const Ctx& c, const PbsParams& P, const u64* ggsw, Src src,
-                                   Out out) {
+template <class F, int LOGN, int K, class Ctx, class Src, class Out>
+TFHE_HD void external_product_team(const Ctx& c, const PbsParams& P, const typename F::elem* ggsw,
+                                   Src src, Out out) {
+  typedef typename F::elem elem;
   constexpr int E = NttShape<LOGN>::kE;
   constexpr int N = 1 << LOGN;
+  constexpr int PARTS = F::kParts;
   const int lane = c.lane();
+  const int me = c.wave();
 
-  u64 accum[K + 1][E];
+  elem accum[PARTS][E];
 #pragma unroll
-  for (int col = 0; col <= K; ++col)
+  for (int q = 0; q < PARTS; ++q)
 #pragma unroll
-    for (int r = 0; r < E; ++r) accum[col][r] = 0;
+    for (int r = 0; r < E; ++r) accum[q][r] = F::zero();
 
-#pragma unroll 1
-  for (int p = 0; p <= K; ++p) {
-    u32 v[E];
+  u32 v[E];
 #pragma unroll
-    for (int r = 0; r < E; ++r) v[r] = round_value(src(p, r * 64 + lane), P.ignored_bits);
-    u32 carry_bits = 0;  // bit r = carry of coefficient r
+  for (int r = 0; r < E; ++r) v[r] = round_value(src(r * 64 + lane), P.ignored_bits);
+  u32 carry_bits = 0;  // bit r = carry of coefficient r
+
+  // Key tiles of one level for my column, in consumption order: idx = s * PARTS + q, s = source
+  // polynomial 0..K, q = part.  Tiles are staged through two register buffers: the loads of tile
+  // idx+1 are issued before the arithmetic of tile idx, and tile 0 of a level is loaded before
+  // that level's forward transform, so no key load sits on the critical path.
+  constexpr int TILES = (K + 1) * PARTS;
+  auto tile_ptr = [&](u32 level, int idx) -> const elem* {
+    const int s = idx / PARTS, q = idx % PARTS;
+    return ggsw + (((size_t)(s * P.levels + level) * (K + 1) + me) * PARTS + q) * N;
+  };
+  elem kbuf[2][E];
+  u32 touched = 0;
 #pragma unroll 1
-    for (u32 t = 0; t < P.levels; ++t) {  // limbs LSB -> MSB; level index counts from the MSB
-      const u32 level = P.levels - 1 - t;
-      const u32 shift = P.first_shift + P.log_base * t;
-      u64 work[E];
+  for (u32 t = 0; t < P.levels; ++t) {  // limbs LSB -> MSB; level index counts from the MSB
+    const u32 level = P.levels - 1 - t;
+    const u32 shift = P.first_shift + P.log_base * t;
+    // Pull the later tiles of this level towards the CU while the forward transform runs: one dword
+    // per 128-byte line = ONE load instruction per 8 KiB tile (the team that leads its XCD otherwise
+    // pays an Infinity-Cache miss per tile inside the MAC phase).
+#pragma unroll
+    for (int idx = 1; idx < TILES; ++idx) {
+      const elem* tile = tile_ptr(level, idx);
+#pragma unroll
+      for (int line = lane * 16; line < N; line += 64 * 16)
+        touched ^= *reinterpret_cast<const u32*>(tile + line);
+    }
+    {
+      const elem* tile = tile_ptr(level, 0);
+#pragma unroll
+      for (int r = 0; r < E; ++r) kbuf[0][r] = tile[spectrum_slot<LOGN>(lane, r)];
+    }
+    c.compiler_fence();
+    {
+      elem work[E];
 #pragma unroll
       for (int r = 0; r < E; ++r) {
         u32 carry = (carry_bits >> r) & 1u;
         const u32 digit = decompose_limb(v[r], shift, P.log_base, carry);
         carry_bits = (carry_bits & ~(1u << r)) | (carry << r);
-        work[r] = gl::from_i32(digit);
+        work[r] = F::from_digit(digit);
       }
-      ntt_forward<LOGN>(c, work);
-      const u64* row = ggsw + (size_t)(p * P.levels + level) * (K + 1) * N;
+      ntt_forward<F, LOGN>(c, work);
+      // publish: element r of lane at [r*64 + lane] (conflict-free 8-byte accesses)
+      elem* mine = c.scratch();
 #pragma unroll
-      for (int col = 0; col <= K; ++col) {
-        const u64* spec = row + (size_t)col * N;
-#pragma unroll
-        for (int r = 0; r < E; ++r)
-          accum[col][r] = gl::add(accum[col][r], gl::mul(work[r], spec[spectrum_slot<LOGN>(lane, r)]));
-      }
+      for (int r = 0; r < E; ++r) mine[r * 64 + lane] = work[r];
     }
-  }
-
-  // compile-time loop: the body is too large for `#pragma unroll`, and a rolled loop would index
-  // accum[] dynamically and push it to scratch memory
-  static_for<0, K + 1>([&](auto col_c) {
-    constexpr int col = decltype(col_c)::value;
-    ntt_inverse<LOGN>(c, accum[col]);
+    c.team_sync();
+    static_for<0, TILES>([&](auto idx_c) {
+      constexpr int idx = decltype(idx_c)::value;
+      constexpr int s = idx / PARTS, q = idx % PARTS;
+      constexpr int cur = idx & 1, nxt = cur ^ 1;
+      if constexpr (idx + 1 < TILES) {
+        const elem* tile = tile_ptr(level, idx + 1);
 #pragma unroll
-    for (int r = 0; r < E; ++r) out(col, r * 64 + lane, gl::lift_mod_2_32(accum[col][r]));
+        for (int r = 0; r < E; ++r) kbuf[nxt][r] = tile[spectrum_slot<LOGN>(lane, r)];
+      }
+      const elem* spec = c.scratch_of(s);
+      elem d[E];
+#pragma unroll
+      for (int r = 0; r < E; ++r) d[r] = spec[r * 64 + lane];
+      c.compiler_fence();  // keep the next tile's loads above this tile's arithmetic
+#pragma unroll
+      for (int r = 0; r < E; ++r) accum[q][r] = F::add(accum[q][r], F::mul(d[r], kbuf[cur][r]));
+    });
+    c.team_sync();  // everyone is done reading before the next transform reuses the buffers
+  }
+  c.keep(touched);
+
+  static_for<0, PARTS>([&](auto part_c) {
+    constexpr int q = decltype(part_c)::value;
+#pragma unroll
+    for (int r = 0; r < E; ++r) accum[q][r] = F::before_inverse(accum[q][r]);
+    ntt_inverse<F, LOGN>(c, accum[q]);
   });
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    elem parts[PARTS];
+#pragma unroll
+    for (int q = 0; q < PARTS; ++q) parts[q] = accum[q][r];
+    out(r * 64 + lane, F::finish(parts));
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
-// Blind rotation of ONE LWE sample (bootstrapping.rs:67-105), accumulator in c.acc() (LDS,
-// (K+1) x N u32, natural order).  On return c.acc() holds the final GLWE accumulator.
+// Blind rotation of ONE LWE sample (bootstrapping.rs:67-105) by a team of K+1 waves.  Wave c keeps
+// polynomial c of the accumulator in its private LDS array c.acc() (N u32, natural order) for all
+// n iterations; on return it holds polynomial c of the final GLWE accumulator.
 // ---------------------------------------------------------------------------------------------
-template <int LOGN, int K, class Ctx>
-TFHE_HD void blind_rotate_wave(const Ctx& c, const PbsParams& P, const u32* lwe /* n+1 */,
-                               const u32* tv /* N, un-encoded */, const u64* bsk /* prepared */) {
+template <class F, int LOGN, int K, class Ctx>
+TFHE_HD void blind_rotate_team(const Ctx& c, const PbsParams& P, const u32* lwe /* n+1 */,
+                               const u32* tv /* N, un-encoded */,
+                               const typename F::elem* bsk /* prepared */) {
   constexpr int E = NttShape<LOGN>::kE;
   constexpr int N = 1 << LOGN;
   const int lane = c.lane();
+  const int me = c.wave();
   u32* acc = c.acc();
 
-  // acc = X^{-b~} * (0, ..., 0, tv << tv_shift)
+  // acc = X^{-b~} * (0, ..., 0, tv << tv_shift): only the body polynomial (wave K) is non-zero
   {
     const u32 b_tilde = switch_modulus_2n(lwe[P.n], LOGN);
     const u32 m = (2u * N - b_tilde) & (2u * N - 1u);
@@ -168,60 +235,69 @@ TFHE_HD void blind_rotate_wave(const Ctx& c, const PbsParams& P, const u32* lwe 
 #pragma unroll
     for (int r = 0; r < E; ++r) {
       const int j = r * 64 + lane;
-#pragma unroll
-      for (int p = 0; p < K; ++p) acc[p * N + j] = 0;
-      const u32 t = tv[(j - deg) & (N - 1)] << P.tv_shift;
-      acc[K * N + j] = (flip ^ (u32)(j < deg)) ? (0u - t) : t;
+      u32 val = 0;
+      if (me == K) {
+        const u32 t = tv[(j - deg) & (N - 1)] << P.tv_shift;
+        val = (flip ^ (u32)(j < deg)) ? (0u - t) : t;
+      }
+      acc[j] = val;
     }
     c.sync();
   }
 
-  const size_t ggsw_words = (size_t)(K + 1) * P.levels * (K + 1) * N;
+  const size_t ggsw_words = (size_t)(K + 1) * P.levels * (K + 1) * F::kParts * N;
 #pragma unroll 1
   for (u32 i = 0; i < P.n; ++i) {
     const u32 a_tilde = c.uniform(switch_modulus_2n(lwe[i], LOGN));
-    // X^0 * acc - acc = 0: every digit is zero and the CMUX returns acc unchanged
-    if (a_tilde == 0) continue;
-    // cmux(ggsw_i, acc, X^{a~} * acc) = external_product(ggsw_i, X^{a~} acc - acc) + acc
-    auto src = [&](int p, int j) -> u32 {
-      return monomial_coeff<LOGN>(acc + p * N, j, a_tilde) - acc[p * N + j];
-    };
-    // all rotated reads happen before the first inverse NTT, so the in-place update is safe
-    auto out = [&](int p, int j, u32 value) { acc[p * N + j] += value; };
-    external_product_wave<LOGN, K>(c, P, bsk + (size_t)i * ggsw_words, src, out);
+    // cmux(ggsw_i, acc, X^{a~} * acc) = external_product(ggsw_i, X^{a~} acc - acc) + acc.
+    // (a~ = 0 gives all-zero digits and leaves acc unchanged; it is not skipped because every wave
+    // of the team has to take part in the barriers.)
+    auto src = [&](int j) -> u32 { return monomial_coeff<LOGN>(acc, j, a_tilde) - acc[j]; };
+    // all rotated reads of acc happen before the first inverse transform: in-place update is safe
+    auto out = [&](int j, u32 value) { acc[j] += value; };
+    external_product_team<F, LOGN, K>(c, P, bsk + (size_t)i * ggsw_words, src, out);
     c.sync();
   }
 }
 
-// sample_extract at index 0 (bootstrapping.rs:122-156) from the LDS accumulator
+// sample_extract at index 0 (bootstrapping.rs:122-156): wave c < K writes the N mask words of its
+// polynomial, wave K writes the body word
 template <int LOGN, int K, class Ctx>
-TFHE_HD void sample_extract_wave(const Ctx& c, u32* out /* K*N + 1 */) {
+TFHE_HD void sample_extract_team(const Ctx& c, u32* out /* K*N + 1 */) {
   constexpr int E = NttShape<LOGN>::kE;
   constexpr int N = 1 << LOGN;
   const int lane = c.lane();
+  const int me = c.wave();
   const u32* acc = c.acc();
-#pragma unroll
-  for (int p = 0; p < K; ++p)
+  if (me < K) {
 #pragma unroll
     for (int r = 0; r < E; ++r) {
       const int x = r * 64 + lane;
-      out[p * N + x] = (x == 0) ? acc[p * N] : (0u - acc[p * N + N - x]);
+      out[me * N + x] = (x == 0) ? acc[0] : (0u - acc[N - x]);
     }
-  if (lane == 0) out[K * N] = acc[K * N];
+  } else if (lane == 0) {
+    out[K * N] = acc[0];
+  }
 }
 
 // Forward NTT of one u32 polynomial of the bootstrapping key into the prepared layout,
 // pre-scaled by N^-1.
-template <int LOGN, class Ctx>
-TFHE_HD void bsk_prepare_wave(const Ctx& c, const u32* poly, u64* spec, u64 n_inv) {
+template <class F, int LOGN, class Ctx>
+TFHE_HD void bsk_prepare_wave(const Ctx& c, const u32* poly, typename F::elem* spec /* [kParts][N] */,
+                              typename F::elem n_inv) {
+  typedef typename F::elem elem;
   constexpr int E = NttShape<LOGN>::kE;
+  constexpr int N = 1 << LOGN;
   const int lane = c.lane();
-  u64 x[E];
+#pragma unroll 1
+  for (int part = 0; part < F::kParts; ++part) {
+    elem x[E];
 #pragma unroll
-  for (int r = 0; r < E; ++r) x[r] = (u64)poly[r * 64 + lane];
-  ntt_forward<LOGN>(c, x);
+    for (int r = 0; r < E; ++r) x[r] = F::from_key_word(poly[r * 64 + lane], part);
+    ntt_forward<F, LOGN>(c, x);
 #pragma unroll
-  for (int r = 0; r < E; ++r) spec[spectrum_slot<LOGN>(lane, r)] = gl::mul(x[r], n_inv);
+    for (int r = 0; r < E; ++r) spec[(size_t)part * N + spectrum_slot<LOGN>(lane, r)] = F::mul(x[r], n_inv);
+  }
 }
 
 }  // namespace tfhe

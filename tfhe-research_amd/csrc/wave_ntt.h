@@ -19,10 +19,14 @@
 // One twiddle table serves both directions: psi_rev[k] = psi^bitrev(k), and
 // psi^-bitrev(h+i) = -psi_rev[2h-1-i], so the inverse butterfly is (V-U) * psi_rev[2h-1-i].
 //
+// The arithmetic is a field policy F (field_gl.h: Goldilocks u64, field_fp.h: 42-bit prime in
+// fp64); elements are 8 bytes in both, so layouts, swizzles and LDS budgets are identical.
+//
 // Ctx (GPU: DeviceWave in kernels.hip; CPU tests: the SIMT emulator in tests/emu) provides
-//   int lane() const;  void sync() const;  u64* scratch() const;  const u64* twiddles() const;
+//   int lane() const;  void sync() const;  elem* scratch() const;  const elem* twiddles() const;
 #pragma once
-#include "goldilocks.h"
+#include "field_fp.h"
+#include "field_gl.h"
 
 namespace tfhe {
 
@@ -62,10 +66,10 @@ TFHE_HD int spectrum_slot(int lane, int r) {
   return (r >> 1) * 128 + lane * 2 + (r & 1);
 }
 
-template <int LOGN, int LO_FROM, int LO_TO, class Ctx>
-TFHE_HD void ntt_transpose(const Ctx& c, u64 (&x)[NttShape<LOGN>::kE]) {
+template <class F, int LOGN, int LO_FROM, int LO_TO, class Ctx>
+TFHE_HD void ntt_transpose(const Ctx& c, typename F::elem (&x)[NttShape<LOGN>::kE]) {
   constexpr int E = NttShape<LOGN>::kE;
-  u64* buf = c.scratch();
+  typename F::elem* buf = c.scratch();
   const int lane = c.lane();
 #pragma unroll
   for (int r = 0; r < E; ++r) buf[ntt_swizzle<LOGN>(ntt_index<LOGN, LO_FROM>(lane, r))] = x[r];
@@ -76,11 +80,12 @@ TFHE_HD void ntt_transpose(const Ctx& c, u64 (&x)[NttShape<LOGN>::kE]) {
 }
 
 // forward stages on bits BHI..BLO (descending) of window [LO, LO+e)
-template <int LOGN, int LO, int BHI, int BLO, class Ctx>
-TFHE_HD void ntt_pass_forward(const Ctx& c, u64 (&x)[NttShape<LOGN>::kE]) {
+template <class F, int LOGN, int LO, int BHI, int BLO, class Ctx>
+TFHE_HD void ntt_pass_forward(const Ctx& c, typename F::elem (&x)[NttShape<LOGN>::kE]) {
+  typedef typename F::elem elem;
   constexpr int E = NttShape<LOGN>::kE;
   constexpr int e = NttShape<LOGN>::kEBits;
-  const u64* tw = c.twiddles();
+  const elem* tw = c.twiddles();
   const int hi = c.lane() >> LO;
 #pragma unroll
   for (int b = BHI; b >= BLO; --b) {
@@ -91,21 +96,22 @@ TFHE_HD void ntt_pass_forward(const Ctx& c, u64 (&x)[NttShape<LOGN>::kE]) {
     for (int r0 = 0; r0 < E; ++r0) {
       if ((r0 >> rb) & 1) continue;
       const int r1 = r0 | (1 << rb);
-      const u64 w = tw[base + (r0 >> (rb + 1))];
-      const u64 u = x[r0];
-      const u64 v = gl::mul(x[r1], w);
-      x[r0] = gl::add(u, v);
-      x[r1] = gl::sub(u, v);
+      const elem w = tw[base + (r0 >> (rb + 1))];
+      const elem u = x[r0];
+      const elem v = F::mul(x[r1], w);
+      x[r0] = F::add(u, v);
+      x[r1] = F::sub(u, v);
     }
   }
 }
 
 // inverse stages on bits BLO..BHI (ascending) of window [LO, LO+e)
-template <int LOGN, int LO, int BHI, int BLO, class Ctx>
-TFHE_HD void ntt_pass_inverse(const Ctx& c, u64 (&x)[NttShape<LOGN>::kE]) {
+template <class F, int LOGN, int LO, int BHI, int BLO, class Ctx>
+TFHE_HD void ntt_pass_inverse(const Ctx& c, typename F::elem (&x)[NttShape<LOGN>::kE]) {
+  typedef typename F::elem elem;
   constexpr int E = NttShape<LOGN>::kE;
   constexpr int e = NttShape<LOGN>::kEBits;
-  const u64* tw = c.twiddles();
+  const elem* tw = c.twiddles();
   const int hi = c.lane() >> LO;
 #pragma unroll
   for (int b = BLO; b <= BHI; ++b) {
@@ -117,49 +123,35 @@ TFHE_HD void ntt_pass_inverse(const Ctx& c, u64 (&x)[NttShape<LOGN>::kE]) {
     for (int r0 = 0; r0 < E; ++r0) {
       if ((r0 >> rb) & 1) continue;
       const int r1 = r0 | (1 << rb);
-      const u64 w = tw[top - (r0 >> (rb + 1))];
-      const u64 u = x[r0];
-      const u64 v = x[r1];
-      x[r0] = gl::add(u, v);
-      x[r1] = gl::mul(gl::sub(v, u), w);
+      const elem w = tw[top - (r0 >> (rb + 1))];
+      const elem u = x[r0];
+      const elem v = x[r1];
+      x[r0] = F::add(u, v);
+      x[r1] = F::mul(F::sub(v, u), w);
     }
   }
 }
 
 // in: x[r] = a[r*64 + lane] (canonical field elements).  out: x[r] = A_bitrev[lane*E + r].
-template <int LOGN, class Ctx>
-TFHE_HD void ntt_forward(const Ctx& c, u64 (&x)[NttShape<LOGN>::kE]) {
+template <class F, int LOGN, class Ctx>
+TFHE_HD void ntt_forward(const Ctx& c, typename F::elem (&x)[NttShape<LOGN>::kE]) {
   using S = NttShape<LOGN>;
-  ntt_pass_forward<LOGN, S::kLo1, LOGN - 1, 6>(c, x);
-  ntt_transpose<LOGN, S::kLo1, S::kLo2>(c, x);
-  ntt_pass_forward<LOGN, S::kLo2, 5, S::kLo2>(c, x);
-  ntt_transpose<LOGN, S::kLo2, S::kLo3>(c, x);
-  ntt_pass_forward<LOGN, S::kLo3, S::kLo2 - 1, 0>(c, x);
+  ntt_pass_forward<F, LOGN, S::kLo1, LOGN - 1, 6>(c, x);
+  ntt_transpose<F, LOGN, S::kLo1, S::kLo2>(c, x);
+  ntt_pass_forward<F, LOGN, S::kLo2, 5, S::kLo2>(c, x);
+  ntt_transpose<F, LOGN, S::kLo2, S::kLo3>(c, x);
+  ntt_pass_forward<F, LOGN, S::kLo3, S::kLo2 - 1, 0>(c, x);
 }
 
 // in: x[r] = A_bitrev[lane*E + r].  out: x[r] = N * a[r*64 + lane] (unscaled inverse).
-template <int LOGN, class Ctx>
-TFHE_HD void ntt_inverse(const Ctx& c, u64 (&x)[NttShape<LOGN>::kE]) {
+template <class F, int LOGN, class Ctx>
+TFHE_HD void ntt_inverse(const Ctx& c, typename F::elem (&x)[NttShape<LOGN>::kE]) {
   using S = NttShape<LOGN>;
-  ntt_pass_inverse<LOGN, S::kLo3, S::kLo2 - 1, 0>(c, x);
-  ntt_transpose<LOGN, S::kLo3, S::kLo2>(c, x);
-  ntt_pass_inverse<LOGN, S::kLo2, 5, S::kLo2>(c, x);
-  ntt_transpose<LOGN, S::kLo2, S::kLo1>(c, x);
-  ntt_pass_inverse<LOGN, S::kLo1, LOGN - 1, 6>(c, x);
-}
-
-// Host-side table: psi_rev[k] = psi^bitrev_LOGN(k), psi = primitive 2N-th root of unity.
-inline void ntt_fill_twiddles(int logn, u64* out /* N */) {
-  const int n = 1 << logn;
-  const u64 psi = gl::root_of_unity(logn + 1);
-  // powers in natural order, then scatter to bit-reversed positions
-  u64 pw = 1;
-  for (int k = 0; k < n; ++k) {
-    int rev = 0;
-    for (int b = 0; b < logn; ++b) rev |= ((k >> b) & 1) << (logn - 1 - b);
-    out[rev] = pw;
-    pw = gl::mul(pw, psi);
-  }
+  ntt_pass_inverse<F, LOGN, S::kLo3, S::kLo2 - 1, 0>(c, x);
+  ntt_transpose<F, LOGN, S::kLo3, S::kLo2>(c, x);
+  ntt_pass_inverse<F, LOGN, S::kLo2, 5, S::kLo2>(c, x);
+  ntt_transpose<F, LOGN, S::kLo2, S::kLo1>(c, x);
+  ntt_pass_inverse<F, LOGN, S::kLo1, LOGN - 1, 6>(c, x);
 }
 
 }  // namespace tfhe
