@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="auto", choices=["auto", "goldilocks", "fp64"])
+    ap.add_argument("--gate", default="", choices=["", "nand", "and", "or", "xor"],
+                    help="step = one homomorphic gate over the batch (boolean.rs: bootstrap(2*ct1 + ct0)) instead of a plain PBS")
     args = ap.parse_args()
 
     import torch
@@ -115,8 +117,12 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # one process per GPU; under torch.distributed.run the group is created even for a single rank so
+    # that the RCCL path (barrier + max-reduction) is the one that runs at every N
+    use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     pkg = entry.load_package()
@@ -148,23 +154,33 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.gate:
+        truth = {"nand": pkg.GATE_NAND, "and": pkg.GATE_AND, "or": pkg.GATE_OR, "xor": pkg.GATE_XOR}[args.gate]
+        lwe2 = rand_words(batch, n + 1)
+
+        def step():
+            ctx.gate(truth, lwe, lwe2, out=out)
+    else:
+        def step():
+            ctx.bootstrap(lwe, tv, out=out)
+
     for _ in range(args.warmup):
-        ctx.bootstrap(lwe, tv, out=out)
+        step()
     barrier()
     br_ms, ks_ms = [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        ctx.bootstrap(lwe, tv, out=out)
+        step()
         b, s = ctx.last_kernel_ms()  # waits for this step's events on the kernel's own stream
         br_ms.append(b)
         ks_ms.append(s)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -179,9 +195,9 @@ def main():
     kernel_name = f"blind_rotate_kernel<{backend_name},{logn},{k}>"
     traffic, traffic_source = pmc_traffic(kernel_name, args.workload, batch)
     result = {
-        "metric": "programmable_bootstraps_per_sec",
+        "metric": "homomorphic_gates_per_sec" if args.gate else "programmable_bootstraps_per_sec",
         "value": value,
-        "unit": "PBS/s",
+        "unit": "gates/s" if args.gate else "PBS/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
@@ -194,7 +210,7 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"{args.workload}: batch {batch}/GPU, N={1 << logn}, k={k}, n={n}, l={pbs[1]}, log2B={pbs[0]}, "
-                        f"KS l={ks[1]} log2B={ks[0]}, log_p={log_p}, identity LUT",
+                        f"KS l={ks[1]} log2B={ks[0]}, log_p={log_p}, " + (f"{args.gate.upper()} gate stream" if args.gate else "identity LUT"),
             "global_batch": batch * world,
             "parallelism": f"dp{world} (independent LWE shards, keys replicated)",
         },
@@ -220,7 +236,7 @@ def main():
         result["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_baseline_seconds)
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

