@@ -75,7 +75,7 @@ int tfhe_params_validate(const tfhe_params *params);
 /* Exact-NTT backends.  Both give identical bits; they differ in speed and in the parameter sets
  * they can lift exactly (checked at context creation, TFHE_ERR_EXACTNESS otherwise):
  *   FP64       42-bit prime, fp64 arithmetic, key split into 16-bit halves; needs
- *              (k+1)*l * N * B * 2^15 < 2^40.9
+ *              (k+1)*l * N * B * 2^15 < 2^40.9 and log_base <= 11
  *   GOLDILOCKS p = 2^64 - 2^32 + 1, u64 arithmetic; needs (k+1)*l * N * B * 2^32 < 2^62
  *   AUTO       FP64 when its bound holds, else GOLDILOCKS (env TFHE_HIP_BACKEND=fp64|goldilocks
  *              overrides AUTO). */

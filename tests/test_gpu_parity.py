@@ -32,7 +32,7 @@ def backend_id(name):
 
 def fp64_exact(p):
     """the fp64 backend's exactness bound (tfhe_hip.h): (k+1) l N B 2^15 < 2^40.9"""
-    return np.log2(p.R) + p.glwe_poly_degree + p.pbs.log_base + 15 < 40.9
+    return np.log2(p.R) + p.glwe_poly_degree + p.pbs.log_base + 15 < 40.9 and p.pbs.log_base <= 11
 
 
 @pytest.fixture(scope="module")

@@ -263,7 +263,9 @@ int tfhe_context_create_with_backend(const tfhe_params* params, int device, int 
   if (!launch::shape_supported(params->glwe_poly_degree, params->glwe_dimension))
     return TFHE_ERR_UNSUPPORTED;
   // exactness of the integer convolution in the chosen field
-  const bool fp_ok = convolution_bits(params, FpField::key_bits()) < FpField::exact_bits();
+  // (the fp64 field also relies on |digit| <= B <= 2^kSmallBits for its reduction-free first stage)
+  const bool fp_ok = convolution_bits(params, FpField::key_bits()) < FpField::exact_bits() &&
+                     params->pbs_decomposer.log_base <= (uint32_t)FpField::kSmallBits;
   const bool gl_ok = convolution_bits(params, GlField::key_bits()) < GlField::exact_bits();
   int field = 0;
   if (backend == TFHE_BACKEND_AUTO) {

@@ -43,6 +43,11 @@ struct FpField {
     const double q = __builtin_rint(h * PINV);
     return __builtin_fma(-q, P, h) + l;
   }
+  // |a| <= 2^kSmallBits (a gadget digit, |d| <= B): a*w is an exact integer below 2^53, no
+  // reduction needed.  The unreduced value (up to 2^52) only ever gets ADDED to later-stage terms
+  // (<= +p/2 per stage) or passes through mul(), which accepts any |a| < 2^53.
+  static constexpr int kSmallBits = 11;
+  TFHE_HD static elem mul_small(elem a, elem w) { return a * w; }
   // x -> balanced residue, |x| < 2^53
   TFHE_HD static elem reduce(elem x) { return __builtin_fma(-__builtin_rint(x * PINV), P, x); }
   TFHE_HD static elem from_digit(u32 d) { return (double)(i32)d; }

@@ -14,6 +14,8 @@ struct GlField {
   TFHE_HD static elem add(elem a, elem b) { return gl::add(a, b); }
   TFHE_HD static elem sub(elem a, elem b) { return gl::sub(a, b); }
   TFHE_HD static elem mul(elem a, elem w) { return gl::mul(a, w); }
+  static constexpr int kSmallBits = 31;  // mul_small is the full product here: any digit qualifies
+  TFHE_HD static elem mul_small(elem a, elem w) { return gl::mul(a, w); }
   // gadget digit (wrapped u32 holding a small signed integer) -> field element
   TFHE_HD static elem from_digit(u32 d) { return gl::from_i32(d); }
   // key word -> field element of spectrum `part`

@@ -123,10 +123,12 @@ TFHE_HD void external_product_team(const Ctx& c, const PbsParams& P, const typen
 #pragma unroll
     for (int r = 0; r < E; ++r) accum[q][r] = F::zero();
 
+  // v[r]: rounded coefficient.  The running carry of the digit chain lives in bit 0 of v[r]: the
+  // lowest kept limb is extracted first (its carry-in is 0 by construction), after that bit 0 is
+  // never part of a limb again (every later limb starts at bit >= log_base >= 1).
   u32 v[E];
 #pragma unroll
   for (int r = 0; r < E; ++r) v[r] = round_value(src(r * 64 + lane), P.ignored_bits);
-  u32 carry_bits = 0;  // bit r = carry of coefficient r
 
   // Key tiles of one level for my column, in consumption order: idx = s * PARTS + q, s = source
   // polynomial 0..K, q = part.  Tiles are staged through two register buffers: the loads of tile
@@ -138,7 +140,6 @@ TFHE_HD void external_product_team(const Ctx& c, const PbsParams& P, const typen
     return ggsw + (((size_t)(s * P.levels + level) * (K + 1) + me) * PARTS + q) * N;
   };
   elem kbuf[2][E];
-  u32 touched = 0;
 #pragma unroll 1
   for (u32 t = 0; t < P.levels; ++t) {  // limbs LSB -> MSB; level index counts from the MSB
     const u32 level = P.levels - 1 - t;
@@ -146,29 +147,38 @@ TFHE_HD void external_product_team(const Ctx& c, const PbsParams& P, const typen
     // Pull the later tiles of this level towards the CU while the forward transform runs: one dword
     // per 128-byte line = ONE load instruction per 8 KiB tile (the team that leads its XCD otherwise
     // pays an Infinity-Cache miss per tile inside the MAC phase).
+    constexpr int LINES = (N * (int)sizeof(elem) / 128 + 63) / 64;  // touch loads per tile
+    u32 touched[TILES > 1 ? (TILES - 1) * LINES : 1];
 #pragma unroll
     for (int idx = 1; idx < TILES; ++idx) {
       const elem* tile = tile_ptr(level, idx);
 #pragma unroll
-      for (int line = lane * 16; line < N; line += 64 * 16)
-        touched ^= *reinterpret_cast<const u32*>(tile + line);
+      for (int w = 0; w < LINES; ++w)
+        touched[(idx - 1) * LINES + w] = *reinterpret_cast<const u32*>(tile + (lane + w * 64) * 16);
     }
     {
       const elem* tile = tile_ptr(level, 0);
 #pragma unroll
       for (int r = 0; r < E; ++r) kbuf[0][r] = tile[spectrum_slot<LOGN>(lane, r)];
     }
+    // "use" the touched dwords right away: holding them until after the MAC phase costs registers,
+    // which this kernel cannot spare (measured: 68.1 ms vs 65.0 ms per 4096-batch)
+#pragma unroll
+    for (int w = 0; w < (TILES > 1 ? (TILES - 1) * LINES : 0); ++w) c.keep(touched[w]);
     c.compiler_fence();
     {
       elem work[E];
+      const u32 carry_mask = (t == 0) ? 0u : 1u;  // wave-uniform
 #pragma unroll
       for (int r = 0; r < E; ++r) {
-        u32 carry = (carry_bits >> r) & 1u;
+        u32 carry = v[r] & carry_mask;
         const u32 digit = decompose_limb(v[r], shift, P.log_base, carry);
-        carry_bits = (carry_bits & ~(1u << r)) | (carry << r);
+        v[r] = (v[r] & ~1u) | carry;
         work[r] = F::from_digit(digit);
       }
-      ntt_forward<F, LOGN>(c, work);
+      // digits are tiny (|d| <= B <= 2^F::kSmallBits, enforced when the context picks the field):
+      // the first butterfly stage uses F::mul_small
+      ntt_forward<F, LOGN, true>(c, work);
       // publish: element r of lane at [r*64 + lane] (conflict-free 8-byte accesses)
       elem* mine = c.scratch();
 #pragma unroll
@@ -194,7 +204,6 @@ TFHE_HD void external_product_team(const Ctx& c, const PbsParams& P, const typen
     });
     c.team_sync();  // everyone is done reading before the next transform reuses the buffers
   }
-  c.keep(touched);
 
   static_for<0, PARTS>([&](auto part_c) {
     constexpr int q = decltype(part_c)::value;

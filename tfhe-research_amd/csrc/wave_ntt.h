@@ -79,8 +79,10 @@ TFHE_HD void ntt_transpose(const Ctx& c, typename F::elem (&x)[NttShape<LOGN>::k
   c.sync();
 }
 
-// forward stages on bits BHI..BLO (descending) of window [LO, LO+e)
-template <class F, int LOGN, int LO, int BHI, int BLO, class Ctx>
+// forward stages on bits BHI..BLO (descending) of window [LO, LO+e).  SMALL_FIRST: the inputs of
+// the first stage handled here are small integers (gadget digits), so its twiddle products may
+// use F::mul_small (exact without reduction in the fp64 field).
+template <class F, int LOGN, int LO, int BHI, int BLO, bool SMALL_FIRST, class Ctx>
 TFHE_HD void ntt_pass_forward(const Ctx& c, typename F::elem (&x)[NttShape<LOGN>::kE]) {
   typedef typename F::elem elem;
   constexpr int E = NttShape<LOGN>::kE;
@@ -98,7 +100,7 @@ TFHE_HD void ntt_pass_forward(const Ctx& c, typename F::elem (&x)[NttShape<LOGN>
       const int r1 = r0 | (1 << rb);
       const elem w = tw[base + (r0 >> (rb + 1))];
       const elem u = x[r0];
-      const elem v = F::mul(x[r1], w);
+      const elem v = (SMALL_FIRST && b == BHI) ? F::mul_small(x[r1], w) : F::mul(x[r1], w);
       x[r0] = F::add(u, v);
       x[r1] = F::sub(u, v);
     }
@@ -133,14 +135,15 @@ TFHE_HD void ntt_pass_inverse(const Ctx& c, typename F::elem (&x)[NttShape<LOGN>
 }
 
 // in: x[r] = a[r*64 + lane] (canonical field elements).  out: x[r] = A_bitrev[lane*E + r].
-template <class F, int LOGN, class Ctx>
+// SMALL_INPUT: every |x[r]| <= 2^F::kSmallBits on entry (gadget digits).
+template <class F, int LOGN, bool SMALL_INPUT = false, class Ctx>
 TFHE_HD void ntt_forward(const Ctx& c, typename F::elem (&x)[NttShape<LOGN>::kE]) {
   using S = NttShape<LOGN>;
-  ntt_pass_forward<F, LOGN, S::kLo1, LOGN - 1, 6>(c, x);
+  ntt_pass_forward<F, LOGN, S::kLo1, LOGN - 1, 6, SMALL_INPUT>(c, x);
   ntt_transpose<F, LOGN, S::kLo1, S::kLo2>(c, x);
-  ntt_pass_forward<F, LOGN, S::kLo2, 5, S::kLo2>(c, x);
+  ntt_pass_forward<F, LOGN, S::kLo2, 5, S::kLo2, false>(c, x);
   ntt_transpose<F, LOGN, S::kLo2, S::kLo3>(c, x);
-  ntt_pass_forward<F, LOGN, S::kLo3, S::kLo2 - 1, 0>(c, x);
+  ntt_pass_forward<F, LOGN, S::kLo3, S::kLo2 - 1, 0, false>(c, x);
 }
 
 // in: x[r] = A_bitrev[lane*E + r].  out: x[r] = N * a[r*64 + lane] (unscaled inverse).
