@@ -41,7 +41,6 @@ struct HostWave {
   u32* acc() const { return t_->acc.data() + (size_t)wave_ * t_->n; }
   const Elem* twiddles() const { return t_->tw.data(); }
   u32 uniform(u32 v) const { return v; }
-  void keep(u32) const {}
   void compiler_fence() const {}
 };
 

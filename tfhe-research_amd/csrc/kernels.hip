@@ -34,8 +34,6 @@ struct DeviceWave {
   __device__ __forceinline__ u32* acc() const { return acc_; }
   __device__ __forceinline__ const Elem* twiddles() const { return tw_; }
   __device__ __forceinline__ u32 uniform(u32 v) const { return __builtin_amdgcn_readfirstlane(v); }
-  // keeps a value (the xor of the cache-line touch loads) alive without any instruction
-  __device__ __forceinline__ void keep(u32 v) const { asm volatile("" ::"v"(v)); }
   // compiler-only barrier: memory operations are not moved across it
   __device__ __forceinline__ void compiler_fence() const { asm volatile("" ::: "memory"); }
 };
@@ -401,15 +399,19 @@ int field_parts(int field) { return field == kFieldFp64 ? FpField::kParts : GlFi
 // (field, log_n, k) -> template instantiation.  TFHE_DEV_CFG2_ONLY builds just the BASELINE cfg2
 // shape (N = 1024, k = 1) for fast iteration on the kernels.
 #if defined(TFHE_DEV_CFG2_ONLY)
+#ifndef TFHE_DEV_LOGN
+#define TFHE_DEV_LOGN 10
+#define TFHE_DEV_K 1
+#endif
 #define TFHE_DISPATCH_LOGN_K(log_n, k, CALL)                                  \
-  if ((k) == 1 && (log_n) == 10) {                                            \
-    constexpr int KK = 1;                                                     \
-    constexpr int LL = 10;                                                    \
+  if ((k) == TFHE_DEV_K && (log_n) == TFHE_DEV_LOGN) {                        \
+    constexpr int KK = TFHE_DEV_K;                                            \
+    constexpr int LL = TFHE_DEV_LOGN;                                         \
     return CALL;                                                              \
   }
 #define TFHE_DISPATCH_LOGN(log_n, CALL)                                       \
-  if ((log_n) == 10) {                                                        \
-    constexpr int LL = 10;                                                    \
+  if ((log_n) == TFHE_DEV_LOGN) {                                             \
+    constexpr int LL = TFHE_DEV_LOGN;                                         \
     return CALL;                                                              \
   }
 #else

@@ -144,27 +144,11 @@ TFHE_HD void external_product_team(const Ctx& c, const PbsParams& P, const typen
   for (u32 t = 0; t < P.levels; ++t) {  // limbs LSB -> MSB; level index counts from the MSB
     const u32 level = P.levels - 1 - t;
     const u32 shift = P.first_shift + P.log_base * t;
-    // Pull the later tiles of this level towards the CU while the forward transform runs: one dword
-    // per 128-byte line = ONE load instruction per 8 KiB tile (the team that leads its XCD otherwise
-    // pays an Infinity-Cache miss per tile inside the MAC phase).
-    constexpr int LINES = (N * (int)sizeof(elem) / 128 + 63) / 64;  // touch loads per tile
-    u32 touched[TILES > 1 ? (TILES - 1) * LINES : 1];
-#pragma unroll
-    for (int idx = 1; idx < TILES; ++idx) {
-      const elem* tile = tile_ptr(level, idx);
-#pragma unroll
-      for (int w = 0; w < LINES; ++w)
-        touched[(idx - 1) * LINES + w] = *reinterpret_cast<const u32*>(tile + (lane + w * 64) * 16);
-    }
     {
       const elem* tile = tile_ptr(level, 0);
 #pragma unroll
       for (int r = 0; r < E; ++r) kbuf[0][r] = tile[spectrum_slot<LOGN>(lane, r)];
     }
-    // "use" the touched dwords right away: holding them until after the MAC phase costs registers,
-    // which this kernel cannot spare (measured: 68.1 ms vs 65.0 ms per 4096-batch)
-#pragma unroll
-    for (int w = 0; w < (TILES > 1 ? (TILES - 1) * LINES : 0); ++w) c.keep(touched[w]);
     c.compiler_fence();
     {
       elem work[E];
