@@ -46,6 +46,7 @@ struct tfhe_context {
   u32* d_glwe_c = nullptr;
   u32* d_tv = nullptr;        // [batch][N] (or [1][N])
   u32* d_tv_gate = nullptr;   // [N] test vector of gate calls
+  u32 gate_truth[4] = {~0u, ~0u, ~0u, ~0u};  // truth table whose test vector d_tv_gate holds
   // generic scratch for the small entry points
   void* d_misc = nullptr;
   size_t misc_bytes = 0;
@@ -743,14 +744,18 @@ int tfhe_gate_batch_device(tfhe_context* ctx, const uint32_t truth[4], const uin
   if (st) return st;
   if (!truth || !ct0 || !ct1 || !lwe_out || batch == 0) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer / empty batch");
   if (!ctx->have_key) return fail(ctx, TFHE_ERR_NO_KEY, "load the bootstrapping key first");
-  std::vector<u32> tv(ctx->N);
-  if ((st = tfhe_construct_test_vector_boolean(&ctx->params, truth, tv.data()))) return st;
-  if ((st = check_tv_host(ctx, tv.data(), ctx->N))) return st;
   if ((st = reserve(ctx, batch))) return st;
   const size_t words = batch * ((size_t)ctx->params.lwe_dimension + 1);
-  // pageable host -> device copy is staged by the runtime before it returns
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_tv_gate, tv.data(), ctx->N * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (std::memcmp(ctx->gate_truth, truth, sizeof(ctx->gate_truth)) != 0) {
+    // first use of this truth table: build its test vector on the host and upload it (this one
+    // call synchronises; repeated calls with the same gate do not)
+    std::vector<u32> tv(ctx->N);
+    if ((st = tfhe_construct_test_vector_boolean(&ctx->params, truth, tv.data()))) return st;
+    if ((st = check_tv_host(ctx, tv.data(), ctx->N))) return st;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_tv_gate, tv.data(), ctx->N * sizeof(u32), hipMemcpyHostToDevice));
+    std::memcpy(ctx->gate_truth, truth, sizeof(ctx->gate_truth));
+  }
   HIP_TRY(ctx, launch::lwe_gate_input(ctx->stream, ct0, ct1, words, ctx->d_lwe_in2));
   return enqueue_bootstrap(ctx, ctx->d_lwe_in2, batch, ctx->d_tv_gate, 1, ctx->d_lwe_big, lwe_out);
 }

@@ -173,7 +173,8 @@ external_product_kernel(PbsParams P, const typename F::elem* __restrict__ tw,
 // Tiled as a wrapping-u32 GEMM: a workgroup owns kKsSamples samples x 64 output columns and walks
 // the big_n*levels key rows in chunks; digits of the chunk are produced once into LDS.
 constexpr int kKsSamples = 32;     // samples per workgroup
-constexpr int kKsCols = 64;        // output columns per workgroup (one per lane)
+constexpr int kKsColsPerLane = 2;  // output columns per lane
+constexpr int kKsCols = 64 * kKsColsPerLane;  // output columns per workgroup
 constexpr int kKsWords = 8;        // mask words decomposed per chunk
 constexpr int kKsPerThread = 8;    // samples per thread (kKsSamples / 4 waves)
 
@@ -184,15 +185,23 @@ __global__ void __launch_bounds__(256) key_switch_kernel(KsParams Kp, u32 big_n,
   u32* dig = reinterpret_cast<u32*>(g_smem);  // [kKsWords*levels][kKsSamples]
   const int tx = (int)(threadIdx.x & 63u);
   const int ty = (int)(threadIdx.x >> 6);
-  const u32 col = blockIdx.x * kKsCols + tx;
   const size_t s0 = (size_t)blockIdx.y * kKsSamples;
   const u32 width = n + 1;
   const u32 levels = Kp.levels;
-  const bool col_ok = col < width;
-
-  u32 acc[kKsPerThread];
+  u32 col[kKsColsPerLane];
+  bool col_ok[kKsColsPerLane];
 #pragma unroll
-  for (int s = 0; s < kKsPerThread; ++s) acc[s] = 0;
+  for (int c = 0; c < kKsColsPerLane; ++c) {
+    col[c] = blockIdx.x * kKsCols + c * 64 + tx;  // lanes read 64 consecutive columns per load
+    col_ok[c] = col[c] < width;
+  }
+
+  // 64-bit accumulators so that every multiply-add is ONE v_mad_u64_u32; only bits 31..0 are kept
+  u64 acc[kKsColsPerLane][kKsPerThread];
+#pragma unroll
+  for (int c = 0; c < kKsColsPerLane; ++c)
+#pragma unroll
+    for (int s = 0; s < kKsPerThread; ++s) acc[c][s] = 0;
 
   for (u32 w0 = 0; w0 < big_n; w0 += kKsWords) {
     // 256 threads decompose 32 samples x 8 words: thread -> (sample = tid / 8, word = tid % 8)
@@ -212,24 +221,34 @@ __global__ void __launch_bounds__(256) key_switch_kernel(KsParams Kp, u32 big_n,
     }
     __syncthreads();
     const u32 rows = ((big_n - w0 < (u32)kKsWords) ? (big_n - w0) : (u32)kKsWords) * levels;
-    const u32* krow = ksk + (size_t)w0 * levels * width + col;
+    const u32* krow = ksk + (size_t)w0 * levels * width;
+#pragma unroll 4
     for (u32 r = 0; r < rows; ++r) {
-      const u32 kv = col_ok ? krow[(size_t)r * width] : 0u;
+      u32 kv[kKsColsPerLane];
+#pragma unroll
+      for (int c = 0; c < kKsColsPerLane; ++c) kv[c] = col_ok[c] ? krow[(size_t)r * width + col[c]] : 0u;
       const u32* d = dig + r * kKsSamples + ty * kKsPerThread;
 #pragma unroll
-      for (int s = 0; s < kKsPerThread; ++s) acc[s] += d[s] * kv;
+      for (int s = 0; s < kKsPerThread; ++s) {
+        const u32 ds = d[s];  // same address in every lane of the wave: LDS broadcast
+#pragma unroll
+        for (int c = 0; c < kKsColsPerLane; ++c) acc[c][s] = (u64)ds * kv[c] + acc[c][s];
+      }
     }
     __syncthreads();
   }
 
-  if (!col_ok) return;
 #pragma unroll
-  for (int s = 0; s < kKsPerThread; ++s) {
-    const size_t sample = s0 + ty * kKsPerThread + s;
-    if (sample >= batch) continue;
-    u32 v = 0u - acc[s];
-    if (col == n) v += lwe_in[sample * ((size_t)big_n + 1) + big_n];
-    lwe_out[sample * width + col] = v;
+  for (int c = 0; c < kKsColsPerLane; ++c) {
+    if (!col_ok[c]) continue;
+#pragma unroll
+    for (int s = 0; s < kKsPerThread; ++s) {
+      const size_t sample = s0 + ty * kKsPerThread + s;
+      if (sample >= batch) continue;
+      u32 v = 0u - (u32)acc[c][s];
+      if (col[c] == n) v += lwe_in[sample * ((size_t)big_n + 1) + big_n];
+      lwe_out[sample * width + col[c]] = v;
+    }
   }
 }
 
@@ -333,10 +352,18 @@ inline int grid_for(size_t work, int block) {
   return (int)g;
 }
 
+// Dynamic LDS above 64 KiB has to be enabled per kernel; done once per kernel and device (the
+// attribute call is not something to repeat on every launch of a short kernel).
 template <typename Kern>
 hipError_t allow_lds(Kern kern, size_t bytes) {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  static bool done[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (done[dev] || bytes <= 64 * 1024) return hipSuccess;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess) done[dev] = true;
+  return e;
 }
 
 template <class F, int LOGN, int K>

@@ -131,15 +131,18 @@ TFHE_HD void external_product_team(const Ctx& c, const PbsParams& P, const typen
   for (int r = 0; r < E; ++r) v[r] = round_value(src(r * 64 + lane), P.ignored_bits);
 
   // Key tiles of one level for my column, in consumption order: idx = s * PARTS + q, s = source
-  // polynomial 0..K, q = part.  Tiles are staged through two register buffers: the loads of tile
-  // idx+1 are issued before the arithmetic of tile idx, and tile 0 of a level is loaded before
-  // that level's forward transform, so no key load sits on the critical path.
+  // polynomial 0..K, q = part.  A tile is consumed in chunks of CH registers; chunks are staged
+  // through two register buffers: the loads of chunk i+1 are issued before the arithmetic of chunk
+  // i, and chunk 0 of a level is loaded before that level's forward transform, so no key load sits
+  // on the critical path.  CH = 16 keeps the staging at 3 x 32 VGPRs whatever E is.
   constexpr int TILES = (K + 1) * PARTS;
+  constexpr int CH = E < 16 ? E : 16;
+  constexpr int CHUNKS = TILES * (E / CH);
   auto tile_ptr = [&](u32 level, int idx) -> const elem* {
     const int s = idx / PARTS, q = idx % PARTS;
     return ggsw + (((size_t)(s * P.levels + level) * (K + 1) + me) * PARTS + q) * N;
   };
-  elem kbuf[2][E];
+  elem kbuf[2][CH];
 #pragma unroll 1
   for (u32 t = 0; t < P.levels; ++t) {  // limbs LSB -> MSB; level index counts from the MSB
     const u32 level = P.levels - 1 - t;
@@ -147,7 +150,7 @@ TFHE_HD void external_product_team(const Ctx& c, const PbsParams& P, const typen
     {
       const elem* tile = tile_ptr(level, 0);
 #pragma unroll
-      for (int r = 0; r < E; ++r) kbuf[0][r] = tile[spectrum_slot<LOGN>(lane, r)];
+      for (int r = 0; r < CH; ++r) kbuf[0][r] = tile[spectrum_slot<LOGN>(lane, r)];
     }
     c.compiler_fence();
     {
@@ -169,22 +172,25 @@ TFHE_HD void external_product_team(const Ctx& c, const PbsParams& P, const typen
       for (int r = 0; r < E; ++r) mine[r * 64 + lane] = work[r];
     }
     c.team_sync();
-    static_for<0, TILES>([&](auto idx_c) {
-      constexpr int idx = decltype(idx_c)::value;
+    static_for<0, CHUNKS>([&](auto ci_c) {
+      constexpr int ci = decltype(ci_c)::value;
+      constexpr int idx = ci / (E / CH), r0 = (ci % (E / CH)) * CH;
       constexpr int s = idx / PARTS, q = idx % PARTS;
-      constexpr int cur = idx & 1, nxt = cur ^ 1;
-      if constexpr (idx + 1 < TILES) {
-        const elem* tile = tile_ptr(level, idx + 1);
+      constexpr int cur = ci & 1, nxt = cur ^ 1;
+      if constexpr (ci + 1 < CHUNKS) {
+        constexpr int nidx = (ci + 1) / (E / CH), nr0 = ((ci + 1) % (E / CH)) * CH;
+        const elem* tile = tile_ptr(level, nidx);
 #pragma unroll
-        for (int r = 0; r < E; ++r) kbuf[nxt][r] = tile[spectrum_slot<LOGN>(lane, r)];
+        for (int r = 0; r < CH; ++r) kbuf[nxt][r] = tile[spectrum_slot<LOGN>(lane, nr0 + r)];
       }
       const elem* spec = c.scratch_of(s);
-      elem d[E];
+      elem d[CH];
 #pragma unroll
-      for (int r = 0; r < E; ++r) d[r] = spec[r * 64 + lane];
-      c.compiler_fence();  // keep the next tile's loads above this tile's arithmetic
+      for (int r = 0; r < CH; ++r) d[r] = spec[(r0 + r) * 64 + lane];
+      c.compiler_fence();  // keep the next chunk's loads above this chunk's arithmetic
 #pragma unroll
-      for (int r = 0; r < E; ++r) accum[q][r] = F::add(accum[q][r], F::mul(d[r], kbuf[cur][r]));
+      for (int r = 0; r < CH; ++r)
+        accum[q][r0 + r] = F::add(accum[q][r0 + r], F::mul(d[r], kbuf[cur][r]));
     });
     c.team_sync();  // everyone is done reading before the next transform reuses the buffers
   }

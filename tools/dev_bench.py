@@ -31,3 +31,14 @@ for _ in range(3):
     ctx.bootstrap(lw, tvd, out=out); ts.append(ctx.last_kernel_ms())
 br = np.mean([t[0] for t in ts]); ks = np.mean([t[1] for t in ts])
 print(f"{os.path.basename(os.environ.get('TFHE_HIP_LIB','default'))} {which}: parity {ok} blind_rotate {br:.2f} ms key_switch {ks:.2f} ms -> {batch / ((br + ks) * 1e-3):.0f} PBS/s", flush=True)
+# key switch parity on random data (oracle)
+rng = np.random.default_rng(1)
+pk = orc.Params(k, logn, 37, orc.Decomposer(*pbs), orc.Decomposer(4, 5))
+ksk_s = rng.integers(0, 1 << 32, size=pk.ksk_shape(), dtype=np.uint64).astype(np.uint32)
+big = rng.integers(0, 1 << 32, size=(45, pk.big_n + 1), dtype=np.uint64).astype(np.uint32)
+bsk_s = np.zeros(pk.bsk_shape(), dtype=np.uint32)
+with m.Context(m.TfheParams(k, logn, 37, m.DecomposerParams(*pbs))) as c2:
+    c2.load_bootstrapping_key(bsk_s, ksk_s)
+    got = c2.key_switch(big)
+okk = all(np.array_equal(got[b], orc.key_switch_lwe(big[b], pk.big_n, pk.n, pk.ks, ksk_s)) for b in (0, 7, 44))
+print("key_switch parity", okk)
