@@ -21,42 +21,44 @@ namespace {
 
 template <class Elem>
 struct HostTeam {
-  int n;
+  int n, g;  // ring degree, waves per polynomial group
   std::vector<Elem> scratch, tw;
   std::vector<u32> acc;
   pthread_barrier_t team_bar;
-  std::vector<pthread_barrier_t> wave_bars;
+  std::vector<pthread_barrier_t> group_bars;
 };
 
 template <class Elem>
 struct HostWave {
   int lane_, wave_;
   HostTeam<Elem>* t_;
-  int lane() const { return lane_; }
-  int wave() const { return wave_; }
-  void sync() const { pthread_barrier_wait(&t_->wave_bars[wave_]); }
+  int tid() const { return (wave_ % t_->g) * 64 + lane_; }
+  int group() const { return wave_ / t_->g; }
+  void poly_sync() const { pthread_barrier_wait(&t_->group_bars[group()]); }
   void team_sync() const { pthread_barrier_wait(&t_->team_bar); }
-  Elem* scratch() const { return t_->scratch.data() + (size_t)wave_ * t_->n; }
+  Elem* scratch() const { return t_->scratch.data() + (size_t)group() * t_->n; }
   const Elem* scratch_of(int s) const { return t_->scratch.data() + (size_t)s * t_->n; }
-  u32* acc() const { return t_->acc.data() + (size_t)wave_ * t_->n; }
+  u32* acc() const { return t_->acc.data() + (size_t)group() * t_->n; }
   const Elem* twiddles() const { return t_->tw.data(); }
   u32 uniform(u32 v) const { return v; }
   void compiler_fence() const {}
 };
 
-// run body(ctx) on a team of `waves` wavefronts x 64 lanes (one OS thread per lane)
+// run body(ctx) on a team of `groups` polynomial groups x g waves x 64 lanes (one OS thread per lane)
 template <class F>
-void run_team(int logn, int waves, const std::function<void(const HostWave<typename F::elem>&)>& body) {
+void run_team(int logn, int groups, int g, const std::function<void(const HostWave<typename F::elem>&)>& body) {
   typedef typename F::elem elem;
   HostTeam<elem> team;
   team.n = 1 << logn;
-  team.scratch.resize((size_t)waves * team.n);
-  team.acc.resize((size_t)waves * team.n);
+  team.g = g;
+  team.scratch.resize((size_t)groups * team.n);
+  team.acc.resize((size_t)groups * team.n);
   team.tw.resize(team.n);
   F::fill_twiddles(logn, team.tw.data());
+  const int waves = groups * g;
   pthread_barrier_init(&team.team_bar, nullptr, waves * kWave);
-  team.wave_bars.resize(waves);
-  for (auto& b : team.wave_bars) pthread_barrier_init(&b, nullptr, kWave);
+  team.group_bars.resize(groups);
+  for (auto& b : team.group_bars) pthread_barrier_init(&b, nullptr, g * kWave);
   std::vector<std::thread> th;
   for (int w = 0; w < waves; ++w)
     for (int l = 0; l < kWave; ++l)
@@ -67,62 +69,64 @@ void run_team(int logn, int waves, const std::function<void(const HostWave<typen
   for (auto& t : th) t.join();
 }
 
-template <class F, int LOGN>
+template <class F, int LOGN, int G>
 void poly_ntt(const typename F::elem* in, typename F::elem* out, int inverse) {
   typedef typename F::elem elem;
-  constexpr int E = NttShape<LOGN>::kE;
-  run_team<F>(LOGN, 1, [&](const HostWave<elem>& w) {
+  constexpr int E = NttShape<LOGN, G>::kE;
+  constexpr int T = NttShape<LOGN, G>::kThreads;
+  run_team<F>(LOGN, 1, G, [&](const HostWave<elem>& w) {
     elem x[E];
     if (!inverse) {
-      for (int r = 0; r < E; ++r) x[r] = in[r * 64 + w.lane()];
-      ntt_forward<F, LOGN>(w, x);
-      for (int r = 0; r < E; ++r) out[w.lane() * E + r] = x[r];
+      for (int r = 0; r < E; ++r) x[r] = in[r * T + w.tid()];
+      ntt_forward<F, LOGN, G>(w, x);
+      for (int r = 0; r < E; ++r) out[w.tid() * E + r] = x[r];
     } else {
-      for (int r = 0; r < E; ++r) x[r] = in[w.lane() * E + r];
-      ntt_inverse<F, LOGN>(w, x);
-      for (int r = 0; r < E; ++r) out[r * 64 + w.lane()] = x[r];
+      for (int r = 0; r < E; ++r) x[r] = in[w.tid() * E + r];
+      ntt_inverse<F, LOGN, G>(w, x);
+      for (int r = 0; r < E; ++r) out[r * T + w.tid()] = x[r];
     }
   });
 }
 
-template <class F, int LOGN>
+template <class F, int LOGN, int G>
 void bsk_prepare(size_t polys, const u32* src, typename F::elem* dst) {
   typedef typename F::elem elem;
   constexpr int N = 1 << LOGN;
   const elem n_inv = F::n_inv(LOGN);
-  run_team<F>(LOGN, 1, [&](const HostWave<elem>& w) {
+  run_team<F>(LOGN, 1, G, [&](const HostWave<elem>& w) {
     for (size_t i = 0; i < polys; ++i)
-      bsk_prepare_wave<F, LOGN>(w, src + i * N, dst + i * N * F::kParts, n_inv);
+      bsk_prepare_wave<F, LOGN, G>(w, src + i * N, dst + i * N * F::kParts, n_inv);
   });
 }
 
-template <class F, int LOGN, int K>
+template <class F, int LOGN, int K, int G>
 void blind_rotate(const PbsParams& P, size_t batch, const u32* lwe, const u32* tv, size_t tv_stride,
                   const typename F::elem* bsk, u32* out_glwe, u32* out_lwe) {
   typedef typename F::elem elem;
   constexpr int N = 1 << LOGN;
-  constexpr int E = NttShape<LOGN>::kE;
-  run_team<F>(LOGN, K + 1, [&](const HostWave<elem>& w) {
+  constexpr int E = NttShape<LOGN, G>::kE;
+  constexpr int T = NttShape<LOGN, G>::kThreads;
+  run_team<F>(LOGN, K + 1, G, [&](const HostWave<elem>& w) {
     for (size_t b = 0; b < batch; ++b) {
-      blind_rotate_team<F, LOGN, K>(w, P, lwe + b * (P.n + 1), tv + b * tv_stride, bsk);
+      blind_rotate_team<F, LOGN, K, G>(w, P, lwe + b * (P.n + 1), tv + b * tv_stride, bsk);
       if (out_glwe)
         for (int r = 0; r < E; ++r)
-          out_glwe[(b * (K + 1) + w.wave()) * N + r * 64 + w.lane()] = w.acc()[r * 64 + w.lane()];
-      if (out_lwe) sample_extract_team<LOGN, K>(w, out_lwe + b * ((size_t)K * N + 1));
+          out_glwe[(b * (K + 1) + w.group()) * N + r * T + w.tid()] = w.acc()[r * T + w.tid()];
+      if (out_lwe) sample_extract_team<LOGN, K, G>(w, out_lwe + b * ((size_t)K * N + 1));
       w.team_sync();
     }
   });
 }
 
-template <class F, int LOGN, int K>
+template <class F, int LOGN, int K, int G>
 void ext_product(const PbsParams& P, const typename F::elem* ggsw, const u32* glwe, u32* out) {
   typedef typename F::elem elem;
   constexpr int N = 1 << LOGN;
-  run_team<F>(LOGN, K + 1, [&](const HostWave<elem>& w) {
-    const int p = w.wave();
+  run_team<F>(LOGN, K + 1, G, [&](const HostWave<elem>& w) {
+    const int p = w.group();
     auto src = [&](int j) -> u32 { return glwe[p * N + j]; };
     auto dst = [&](int j, u32 v) { out[p * N + j] = v; };
-    external_product_team<F, LOGN, K>(w, P, ggsw, src, dst);
+    external_product_team<F, LOGN, K, G>(w, P, ggsw, src, dst);
   });
 }
 
@@ -141,31 +145,31 @@ PbsParams make_params(u32 n, u32 k, u32 log_n, u32 log_p, u32 padding, u32 log_b
 
 }  // namespace
 
-#define DISPATCH_LOGN(logn, CALL)            \
-  switch (logn) {                            \
-    case 9: { constexpr int L = 9; CALL; break; }   \
-    case 10: { constexpr int L = 10; CALL; break; } \
-    case 11: { constexpr int L = 11; CALL; break; } \
-    default: return 1;                       \
-  }
+// (logn, g): g = waves per polynomial; supported: (9,1) (10,1) (11,1) (11,2)
+#define DISPATCH_LOGN(logn, g, CALL)                                     \
+  if ((logn) == 9 && (g) == 1) { constexpr int L = 9, GG = 1; CALL; }    \
+  else if ((logn) == 10 && (g) == 1) { constexpr int L = 10, GG = 1; CALL; } \
+  else if ((logn) == 11 && (g) == 1) { constexpr int L = 11, GG = 1; CALL; } \
+  else if ((logn) == 11 && (g) == 2) { constexpr int L = 11, GG = 2; CALL; } \
+  else return 1;
 
 // field: 1 = Goldilocks (u64 elements), 2 = fp64 prime (double elements); buffers are 8-byte words
 #define DISPATCH_FIELD(field, CALL)                    \
-  if ((field) == 1) { typedef GlField FF; CALL; }      \
-  else if ((field) == 2) { typedef FpField FF; CALL; } \
+  if ((field) == 1) { typedef GlField FF; CALL }       \
+  else if ((field) == 2) { typedef FpField FF; CALL }  \
   else return 3;
 
 extern "C" {
 
 int emu_field_parts(int field) { return field == 2 ? FpField::kParts : GlField::kParts; }
 
-int emu_poly_ntt(int field, int logn, const void* in, void* out, int inverse) {
-  DISPATCH_FIELD(field, DISPATCH_LOGN(logn, (poly_ntt<FF, L>((const FF::elem*)in, (FF::elem*)out, inverse))));
+int emu_poly_ntt(int field, int logn, int g, const void* in, void* out, int inverse) {
+  DISPATCH_FIELD(field, DISPATCH_LOGN(logn, g, (poly_ntt<FF, L, GG>((const FF::elem*)in, (FF::elem*)out, inverse))));
   return 0;
 }
 
 int emu_twiddles(int field, int logn, void* out) {
-  DISPATCH_FIELD(field, FF::fill_twiddles(logn, (FF::elem*)out));
+  DISPATCH_FIELD(field, FF::fill_twiddles(logn, (FF::elem*)out););
   return 0;
 }
 
@@ -189,26 +193,26 @@ void emu_fp_to_u32_many(const double* a, u32* out, size_t len) {
 }
 double emu_fp_from_key_word(u32 w, int part) { return FpField::from_key_word(w, part); }
 
-int emu_bsk_prepare(int field, int logn, size_t polys, const u32* src, void* dst) {
-  DISPATCH_FIELD(field, DISPATCH_LOGN(logn, (bsk_prepare<FF, L>(polys, src, (FF::elem*)dst))));
+int emu_bsk_prepare(int field, int logn, int g, size_t polys, const u32* src, void* dst) {
+  DISPATCH_FIELD(field, DISPATCH_LOGN(logn, g, (bsk_prepare<FF, L, GG>(polys, src, (FF::elem*)dst))));
   return 0;
 }
 
-int emu_blind_rotate(int field, u32 n, u32 k, u32 logn, u32 log_p, u32 padding, u32 log_base,
+int emu_blind_rotate(int field, int g, u32 n, u32 k, u32 logn, u32 log_p, u32 padding, u32 log_base,
                      u32 levels, size_t batch, const u32* lwe, const u32* tv, size_t tv_stride,
                      const void* bsk, u32* out_glwe, u32* out_lwe) {
   PbsParams P = make_params(n, k, logn, log_p, padding, log_base, levels);
-  if (k == 1) { DISPATCH_FIELD(field, DISPATCH_LOGN(logn, (blind_rotate<FF, L, 1>(P, batch, lwe, tv, tv_stride, (const FF::elem*)bsk, out_glwe, out_lwe)))); }
-  else if (k == 2) { DISPATCH_FIELD(field, DISPATCH_LOGN(logn, (blind_rotate<FF, L, 2>(P, batch, lwe, tv, tv_stride, (const FF::elem*)bsk, out_glwe, out_lwe)))); }
+  if (k == 1) { DISPATCH_FIELD(field, DISPATCH_LOGN(logn, g, (blind_rotate<FF, L, 1, GG>(P, batch, lwe, tv, tv_stride, (const FF::elem*)bsk, out_glwe, out_lwe)))); }
+  else if (k == 2) { DISPATCH_FIELD(field, DISPATCH_LOGN(logn, g, (blind_rotate<FF, L, 2, GG>(P, batch, lwe, tv, tv_stride, (const FF::elem*)bsk, out_glwe, out_lwe)))); }
   else return 2;
   return 0;
 }
 
-int emu_external_product(int field, u32 k, u32 logn, u32 log_base, u32 levels, const void* ggsw,
+int emu_external_product(int field, int g, u32 k, u32 logn, u32 log_base, u32 levels, const void* ggsw,
                          const u32* glwe, u32* out) {
   PbsParams P = make_params(0, k, logn, 2, 1, log_base, levels);
-  if (k == 1) { DISPATCH_FIELD(field, DISPATCH_LOGN(logn, (ext_product<FF, L, 1>(P, (const FF::elem*)ggsw, glwe, out)))); }
-  else if (k == 2) { DISPATCH_FIELD(field, DISPATCH_LOGN(logn, (ext_product<FF, L, 2>(P, (const FF::elem*)ggsw, glwe, out)))); }
+  if (k == 1) { DISPATCH_FIELD(field, DISPATCH_LOGN(logn, g, (ext_product<FF, L, 1, GG>(P, (const FF::elem*)ggsw, glwe, out)))); }
+  else if (k == 2) { DISPATCH_FIELD(field, DISPATCH_LOGN(logn, g, (ext_product<FF, L, 2, GG>(P, (const FF::elem*)ggsw, glwe, out)))); }
   else return 2;
   return 0;
 }

@@ -90,11 +90,11 @@ def test_wave_ntt_matches_model(emu, logn):
     rng = np.random.default_rng(logn)
     a = np.array([int(x) % P for x in rng.integers(0, 1 << 64, size=n, dtype=np.uint64)], dtype=np.uint64)
     out = np.zeros_like(a)
-    assert emu.emu_poly_ntt(GL, logn, p64(a), p64(out), 0) == 0
+    assert emu.emu_poly_ntt(GL, logn, 1, p64(a), p64(out), 0) == 0
     ref = ntt_model.ntt_ref(a.tolist(), logn, fwd)
     assert out.tolist() == ref
     back = np.zeros_like(a)
-    assert emu.emu_poly_ntt(GL, logn, p64(out), p64(back), 1) == 0
+    assert emu.emu_poly_ntt(GL, logn, 1, p64(out), p64(back), 1) == 0
     assert back.tolist() == [x * n % P for x in a.tolist()]  # unscaled inverse
 
 
@@ -132,8 +132,8 @@ def test_fp_field_arithmetic(emu):
         assert (int(lo) + (int(hi) << 16) - word) % (1 << 32) == 0
 
 
-@pytest.mark.parametrize("logn", [9, 10, 11])
-def test_fp_wave_ntt_roundtrip_and_convolution(emu, logn):
+@pytest.mark.parametrize("logn,g", [(9, 1), (10, 1), (11, 1), (11, 2)])
+def test_fp_wave_ntt_roundtrip_and_convolution(emu, logn, g):
     """fp64 field transform: forward of two small polynomials, pointwise product, inverse = exact
     negacyclic convolution (checked with numpy integers)."""
     n = 1 << logn
@@ -142,14 +142,14 @@ def test_fp_wave_ntt_roundtrip_and_convolution(emu, logn):
     a = rng.integers(-256, 257, size=n).astype(np.float64)
     b = rng.integers(-(1 << 15), (1 << 15) + 1, size=n).astype(np.float64)
     fa, fb = np.zeros(n), np.zeros(n)
-    assert emu.emu_poly_ntt(FP, logn, pd(a), pd(fa), 0) == 0
-    assert emu.emu_poly_ntt(FP, logn, pd(b), pd(fb), 0) == 0
+    assert emu.emu_poly_ntt(FP, logn, g, pd(a), pd(fa), 0) == 0
+    assert emu.emu_poly_ntt(FP, logn, g, pd(b), pd(fb), 0) == 0
     assert np.abs(fa).max() <= 6.2 * p and np.abs(fb).max() <= 6.2 * p
     ninv = pow(n, p - 2, p)
     prod = np.array([float(((int(x) * int(y) % p) * ninv) % p) for x, y in zip(fa, fb)])
     prod = np.where(prod > p // 2, prod - p, prod)
     back = np.zeros(n)
-    assert emu.emu_poly_ntt(FP, logn, pd(prod), pd(back), 1) == 0
+    assert emu.emu_poly_ntt(FP, logn, g, pd(prod), pd(back), 1) == 0
     assert np.abs(back).max() < 2 ** 53
     ai, bi = a.astype(np.int64), b.astype(np.int64)
     full = np.convolve(ai, bi)
@@ -159,41 +159,43 @@ def test_fp_wave_ntt_roundtrip_and_convolution(emu, logn):
     assert np.array_equal(got, want % p)
 
 
-def prepared(emu, field, params, bsk):
+def prepared(emu, field, params, bsk, g=1):
     flat = np.ascontiguousarray(bsk, dtype=np.uint32).reshape(-1, params.N)
     parts = emu.emu_field_parts(field)
     out = np.zeros((flat.shape[0], parts, params.N), dtype=np.uint64)
-    assert emu.emu_bsk_prepare(field, params.glwe_poly_degree, C.c_size_t(flat.shape[0]), p32(flat), p64(out)) == 0
+    assert emu.emu_bsk_prepare(field, params.glwe_poly_degree, g, C.c_size_t(flat.shape[0]), p32(flat), p64(out)) == 0
     return out
 
 
 CASES = [
-    # k, logN, n, (logB, levels), log_p
-    (1, 9, 3, (8, 2), 2),
-    (1, 10, 3, (7, 3), 2),   # BASELINE cfg2 shape, misaligned base (bits 28..31 dropped)
-    (2, 9, 2, (4, 6), 2),    # reference default shape
-    (2, 11, 1, (8, 4), 4),   # BASELINE cfg5 shape
+    # k, logN, n, (logB, levels), log_p, waves per polynomial
+    (1, 9, 3, (8, 2), 2, 1),
+    (1, 10, 3, (7, 3), 2, 1),   # BASELINE cfg2 shape, misaligned base (bits 28..31 dropped)
+    (2, 9, 2, (4, 6), 2, 1),    # reference default shape
+    (2, 11, 1, (8, 4), 4, 1),   # BASELINE cfg5 shape, one wave per polynomial
+    (2, 11, 1, (8, 4), 4, 2),   # BASELINE cfg5 shape, two waves per polynomial (the shipped mapping)
+    (1, 11, 2, (4, 7), 2, 2),
 ]
 
 
 @pytest.mark.parametrize("field", FIELDS)
-@pytest.mark.parametrize("k,logn,n,pbs,log_p", CASES)
-def test_external_product_vs_oracle(emu, oracle, field, k, logn, n, pbs, log_p):
+@pytest.mark.parametrize("k,logn,n,pbs,log_p,g", CASES)
+def test_external_product_vs_oracle(emu, oracle, field, k, logn, n, pbs, log_p, g):
     params = oracle.Params(k, logn, n, oracle.Decomposer(*pbs), log_p=log_p)
     rng = np.random.default_rng(11 * logn + k)
     ggsw = rng.integers(0, 1 << 32, size=(params.R, k + 1, params.N), dtype=np.uint64).astype(np.uint32)
     glwe = rng.integers(0, 1 << 32, size=(k + 1, params.N), dtype=np.uint64).astype(np.uint32)
     # hit the digit == B and digit == -B/2 paths in every polynomial
     glwe[:, :4] = [0xFFFFFFFF, 0x7FFFFFFF, 0x80000000, 0xF8F8F8F8]
-    spec = prepared(emu, field, params, ggsw)
+    spec = prepared(emu, field, params, ggsw, g)
     out = np.zeros_like(glwe)
-    assert emu.emu_external_product(field, k, logn, pbs[0], pbs[1], p64(spec), p32(glwe), p32(out)) == 0
+    assert emu.emu_external_product(field, g, k, logn, pbs[0], pbs[1], p64(spec), p32(glwe), p32(out)) == 0
     assert np.array_equal(out, oracle.external_product(params, ggsw, glwe))
 
 
 @pytest.mark.parametrize("field", FIELDS)
-@pytest.mark.parametrize("k,logn,pbs", [(1, 10, (7, 3)), (2, 11, (8, 4)), (2, 9, (4, 6)), (1, 9, (16, 2))])
-def test_external_product_worst_case_magnitudes(emu, oracle, field, k, logn, pbs):
+@pytest.mark.parametrize("k,logn,pbs,g", [(1, 10, (7, 3), 1), (2, 11, (8, 4), 2), (2, 9, (4, 6), 1), (1, 9, (16, 2), 1)])
+def test_external_product_worst_case_magnitudes(emu, oracle, field, k, logn, pbs, g):
     """Adversarial inputs that drive the integer convolution to its bound: every digit at +B or
     -B/2 and every key word at 0x7FFF8000-type extremes (both 16-bit halves maximal), aligned so
     that the negacyclic sums do not cancel.  The exact-NTT bound must hold, not just typical inputs."""
@@ -219,15 +221,15 @@ def test_external_product_worst_case_magnitudes(emu, oracle, field, k, logn, pbs
         glwe = np.full((k + 1, N), glwe_word, dtype=np.uint32)
         # negacyclic sign pattern: make the key alternate sign across the wrap so sums add up at coefficient 0
         ggsw[:, :, 1:] = (np.uint32(0) - ggsw[:, :, 1:]).astype(np.uint32)
-        spec = prepared(emu, field, params, ggsw)
+        spec = prepared(emu, field, params, ggsw, g)
         out = np.zeros_like(glwe)
-        assert emu.emu_external_product(field, k, logn, log_base, levels, p64(spec), p32(glwe), p32(out)) == 0
+        assert emu.emu_external_product(field, g, k, logn, log_base, levels, p64(spec), p32(glwe), p32(out)) == 0
         assert np.array_equal(out, oracle.external_product(params, ggsw, glwe)), hex(key_word)
 
 
 @pytest.mark.parametrize("field", FIELDS)
-@pytest.mark.parametrize("k,logn,n,pbs,log_p", CASES)
-def test_blind_rotate_and_extract_vs_oracle(emu, oracle, field, k, logn, n, pbs, log_p):
+@pytest.mark.parametrize("k,logn,n,pbs,log_p,g", CASES)
+def test_blind_rotate_and_extract_vs_oracle(emu, oracle, field, k, logn, n, pbs, log_p, g):
     params = oracle.Params(k, logn, n, oracle.Decomposer(*pbs), log_p=log_p)
     batch = 2
     lut = np.random.default_rng(5).integers(0, 1 << log_p, size=1 << log_p)
@@ -235,10 +237,10 @@ def test_blind_rotate_and_extract_vs_oracle(emu, oracle, field, k, logn, n, pbs,
     lwe = lwe.copy()
     lwe[0, 0] = 0            # a~ = 0: the skipped iteration
     lwe[1, n] = 0xFFFFFFFF   # b~ rounds up to 2N and wraps to 0
-    spec = prepared(emu, field, params, bsk)
+    spec = prepared(emu, field, params, bsk, g)
     glwe = np.zeros((batch, k + 1, params.N), dtype=np.uint32)
     ext = np.zeros((batch, params.big_n + 1), dtype=np.uint32)
-    rc = emu.emu_blind_rotate(field, n, k, logn, log_p, 1, pbs[0], pbs[1], C.c_size_t(batch), p32(lwe), p32(tv),
+    rc = emu.emu_blind_rotate(field, g, n, k, logn, log_p, 1, pbs[0], pbs[1], C.c_size_t(batch), p32(lwe), p32(tv),
                               C.c_size_t(0), p64(spec), p32(glwe), p32(ext))
     assert rc == 0
     for b in range(batch):

@@ -8,28 +8,41 @@
 namespace tfhe {
 namespace {
 
-template <class Elem>
+// waves per polynomial: one, except N = 2048 where a lane would otherwise hold 32 elements per array
+template <int LOGN>
+struct GroupOf {
+  static constexpr int value = (LOGN >= 11) ? 2 : 1;
+};
+
+template <class Elem, int G>
 struct DeviceWave {
-  unsigned char* team_base_;  // LDS of wave 0 of this team
+  unsigned char* team_base_;  // LDS of group 0 of this team
   Elem* scratch_;
   u32* acc_;
   const Elem* tw_;
-  int wave_;
-  unsigned wave_stride_;      // bytes of LDS per wave
-  __device__ __forceinline__ int lane() const { return (int)(threadIdx.x & 63u); }
-  __device__ __forceinline__ int wave() const { return wave_; }
-  // Orders this wave's LDS stores before its later LDS loads.  All 64 lanes run in lockstep and
-  // the LDS pipeline is in-order per wave, so only the compiler has to be fenced.
-  __device__ __forceinline__ void sync() const {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  int group_;                 // polynomial / output column of my group
+  unsigned group_stride_;     // bytes of LDS per group
+  // thread index inside my polynomial's group of G waves
+  __device__ __forceinline__ int tid() const { return (int)(threadIdx.x & (64u * G - 1u)); }
+  __device__ __forceinline__ int group() const { return group_; }
+  // Orders LDS stores of my polynomial's group before its later LDS loads.  G == 1: all 64 lanes run
+  // in lockstep and the LDS pipeline is in-order per wave, so only the compiler has to be fenced.
+  // G > 1: the group spans waves, so this is the workgroup barrier (every wave of the workgroup runs
+  // the same transforms, hence the same number of barriers).
+  __device__ __forceinline__ void poly_sync() const {
+    if (G == 1) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+      __syncthreads();
+    }
   }
-  // workgroup barrier: the team of K+1 waves that shares one sample IS the workgroup
+  // workgroup barrier: the team of K+1 groups that shares one sample IS the workgroup
   __device__ __forceinline__ void team_sync() const { __syncthreads(); }
   __device__ __forceinline__ Elem* scratch() const { return scratch_; }
   __device__ __forceinline__ const Elem* scratch_of(int s) const {
-    return reinterpret_cast<const Elem*>(team_base_ + (size_t)s * wave_stride_);
+    return reinterpret_cast<const Elem*>(team_base_ + (size_t)s * group_stride_);
   }
   __device__ __forceinline__ u32* acc() const { return acc_; }
   __device__ __forceinline__ const Elem* twiddles() const { return tw_; }
@@ -39,40 +52,40 @@ struct DeviceWave {
 };
 
 #ifndef TFHE_WAVES_PER_SIMD_GL
-#define TFHE_WAVES_PER_SIMD_GL 3
+#define TFHE_WAVES_PER_SIMD_GL 2
 #endif
 #ifndef TFHE_WAVES_PER_SIMD_FP
-#define TFHE_WAVES_PER_SIMD_FP 3
+#define TFHE_WAVES_PER_SIMD_FP 2
 #endif
 
-// One workgroup = one team = K+1 waves = one LWE sample.
-// LDS (dynamic, 16-B aligned base, no static LDS): [ twiddles N x 8 B ][ wave w: transpose/exchange
-// buffer N x 8 B | accumulator polynomial N x 4 B ] for w = 0..K
+// One workgroup = one team = K+1 polynomial groups of G waves = one LWE sample.
+// LDS (dynamic, 16-B aligned base, no static LDS): [ twiddles N x 8 B ][ group c: transpose/exchange
+// buffer N x 8 B | accumulator polynomial N x 4 B ] for c = 0..K
 template <int LOGN, int K>
 struct TeamCfg {
   static constexpr int N = 1 << LOGN;
-  static constexpr int kWaves = K + 1;
+  static constexpr int G = GroupOf<LOGN>::value;
+  static constexpr int kWaves = (K + 1) * G;
   static constexpr int kThreads = kWaves * 64;
-  static constexpr unsigned kWaveLds = (unsigned)N * 8u + (unsigned)N * 4u;
-  static constexpr size_t kLds = (size_t)N * 8 + (size_t)kWaves * kWaveLds;
-  // register budget: E = N/64 elements per array per lane
-  static constexpr int kMinWavesGl = (LOGN == 11) ? 2 : TFHE_WAVES_PER_SIMD_GL;
-  static constexpr int kMinWavesFp = (LOGN == 11) ? 2 : TFHE_WAVES_PER_SIMD_FP;
+  static constexpr unsigned kGroupLds = (unsigned)N * 8u + (unsigned)N * 4u;
+  static constexpr size_t kLds = (size_t)N * 8 + (size_t)(K + 1) * kGroupLds;
+  static constexpr int kMinWavesGl = TFHE_WAVES_PER_SIMD_GL;
+  static constexpr int kMinWavesFp = TFHE_WAVES_PER_SIMD_FP;
 };
 
 template <class F, int LOGN, int K>
-__device__ __forceinline__ DeviceWave<typename F::elem> make_wave(unsigned char* smem,
-                                                                   const typename F::elem* tw_global) {
+__device__ __forceinline__ DeviceWave<typename F::elem, GroupOf<LOGN>::value> make_wave(
+    unsigned char* smem, const typename F::elem* tw_global) {
   typedef typename F::elem elem;
   using C = TeamCfg<LOGN, K>;
   elem* tw = reinterpret_cast<elem*>(smem);
   for (int i = threadIdx.x; i < C::N; i += blockDim.x) tw[i] = tw_global[i];
   __syncthreads();
-  DeviceWave<elem> w;
-  w.wave_ = (int)(threadIdx.x >> 6);
-  w.wave_stride_ = C::kWaveLds;
+  DeviceWave<elem, C::G> w;
+  w.group_ = (int)(threadIdx.x / (64u * C::G));
+  w.group_stride_ = C::kGroupLds;
   w.team_base_ = smem + (size_t)C::N * 8;
-  unsigned char* base = w.team_base_ + (size_t)w.wave_ * C::kWaveLds;
+  unsigned char* base = w.team_base_ + (size_t)w.group_ * C::kGroupLds;
   w.tw_ = tw;
   w.scratch_ = reinterpret_cast<elem*>(base);
   w.acc_ = reinterpret_cast<u32*>(base + (size_t)C::N * 8);
@@ -82,6 +95,7 @@ __device__ __forceinline__ DeviceWave<typename F::elem> make_wave(unsigned char*
 extern __shared__ __attribute__((aligned(16))) unsigned char g_smem[];
 
 // ------------------------------------------------------------------------------ bsk_prepare
+// one polynomial per group of G waves; kPolysPerBlock groups per workgroup
 template <class F, int LOGN>
 __global__ void __launch_bounds__(256) bsk_prepare_kernel(const typename F::elem* __restrict__ tw,
                                                          const u32* __restrict__ polys,
@@ -90,20 +104,27 @@ __global__ void __launch_bounds__(256) bsk_prepare_kernel(const typename F::elem
                                                          typename F::elem n_inv) {
   typedef typename F::elem elem;
   constexpr int N = 1 << LOGN;
+  constexpr int G = GroupOf<LOGN>::value;
   elem* twl = reinterpret_cast<elem*>(g_smem);
   for (int i = threadIdx.x; i < N; i += blockDim.x) twl[i] = tw[i];
   __syncthreads();
-  const int wave = (int)(threadIdx.x >> 6);
-  const size_t poly = (size_t)blockIdx.x * (blockDim.x >> 6) + wave;
-  if (poly >= poly_count) return;
-  DeviceWave<elem> w;
-  w.wave_ = 0;
-  w.wave_stride_ = 0;
+  const int group = (int)(threadIdx.x / (64u * G));
+  const int groups = (int)(blockDim.x / (64u * G));
+  // For G > 1 the transform contains workgroup barriers, so every group of the block has to run it:
+  // a group past the end of the list redoes the last polynomial (same values to the same addresses).
+  size_t poly = (size_t)blockIdx.x * groups + group;
+  if (poly >= poly_count) {
+    if (G == 1) return;
+    poly = poly_count - 1;
+  }
+  DeviceWave<elem, G> w;
+  w.group_ = 0;
+  w.group_stride_ = 0;
   w.team_base_ = nullptr;
   w.tw_ = twl;
-  w.scratch_ = reinterpret_cast<elem*>(g_smem + (size_t)N * 8 + (size_t)wave * N * 8);
+  w.scratch_ = reinterpret_cast<elem*>(g_smem + (size_t)N * 8 + (size_t)group * N * 8);
   w.acc_ = nullptr;
-  bsk_prepare_wave<F, LOGN>(w, polys + poly * N, spectra + poly * N * F::kParts, n_inv);
+  bsk_prepare_wave<F, LOGN, G>(w, polys + poly * N, spectra + poly * N * F::kParts, n_inv);
 }
 
 // ------------------------------------------------------------------------------ blind rotation
@@ -117,19 +138,21 @@ blind_rotate_kernel(PbsParams P, const typename F::elem* __restrict__ tw,
                     u32* __restrict__ glwe_out, u32* __restrict__ lwe_extracted) {
   using C = TeamCfg<LOGN, K>;
   constexpr int N = C::N;
-  constexpr int E = NttShape<LOGN>::kE;
+  constexpr int G = C::G;
+  constexpr int E = NttShape<LOGN, G>::kE;
+  constexpr int T = NttShape<LOGN, G>::kThreads;
   auto w = make_wave<F, LOGN, K>(g_smem, tw);
   const size_t sample = blockIdx.x;  // grid = batch: no ragged tail, every wave runs every barrier
 
-  blind_rotate_team<F, LOGN, K>(w, P, lwe_in + sample * (P.n + 1), tv + sample * tv_stride, bsk);
+  blind_rotate_team<F, LOGN, K, G>(w, P, lwe_in + sample * (P.n + 1), tv + sample * tv_stride, bsk);
 
-  const int lane = w.lane();
+  const int tid = w.tid();
   if (glwe_out) {
-    u32* dst = glwe_out + (sample * (size_t)(K + 1) + w.wave()) * N;
+    u32* dst = glwe_out + (sample * (size_t)(K + 1) + w.group()) * N;
 #pragma unroll
-    for (int r = 0; r < E; ++r) dst[r * 64 + lane] = w.acc()[r * 64 + lane];
+    for (int r = 0; r < E; ++r) dst[r * T + tid] = w.acc()[r * T + tid];
   }
-  if (lwe_extracted) sample_extract_team<LOGN, K>(w, lwe_extracted + sample * ((size_t)K * N + 1));
+  if (lwe_extracted) sample_extract_team<LOGN, K, G>(w, lwe_extracted + sample * ((size_t)K * N + 1));
 }
 
 // ------------------------------------------------------------------------------ external product
@@ -143,16 +166,17 @@ external_product_kernel(PbsParams P, const typename F::elem* __restrict__ tw,
                         u32* glwe_out) {
   using C = TeamCfg<LOGN, K>;
   constexpr int N = C::N;
+  constexpr int G = C::G;
   auto w = make_wave<F, LOGN, K>(g_smem, tw);
   const size_t sample = blockIdx.x;
-  const size_t poly = (sample * (size_t)(K + 1) + w.wave()) * N;  // my polynomial / my output column
+  const size_t poly = (sample * (size_t)(K + 1) + w.group()) * N;  // my polynomial / my output column
   const typename F::elem* g = ggsw + sample * ggsw_stride_words;
   u32* dst = glwe_out + poly;
   if (cmux_ct0 == nullptr) {
     const u32* in = glwe_in + poly;
     auto src = [&](int j) -> u32 { return in[j]; };
     auto out = [&](int j, u32 v) { dst[j] = v; };
-    external_product_team<F, LOGN, K>(w, P, g, src, out);
+    external_product_team<F, LOGN, K, G>(w, P, g, src, out);
   } else {
     const u32* c0 = cmux_ct0 + poly;
     u32* c1 = ct1_inout + poly;
@@ -164,7 +188,7 @@ external_product_kernel(PbsParams P, const typename F::elem* __restrict__ tw,
       return d;
     };
     auto out = [&](int j, u32 v) { dst[j] = v + c0[j]; };
-    external_product_team<F, LOGN, K>(w, P, g, src, out);
+    external_product_team<F, LOGN, K, G>(w, P, g, src, out);
   }
 }
 
@@ -400,15 +424,16 @@ template <class F, int LOGN>
 hipError_t launch_bsk_prepare(hipStream_t s, const void* tw_v, const u32* polys, size_t poly_count,
                               void* spectra_v) {
   constexpr int N = 1 << LOGN;
-  constexpr int waves = 4;
-  const size_t lds = (size_t)N * 8 * (1 + waves);
+  constexpr int G = GroupOf<LOGN>::value;
+  constexpr int groups = 4 / G;  // polynomials per 256-thread workgroup
+  const size_t lds = (size_t)N * 8 * (1 + groups);
   auto tw = static_cast<const typename F::elem*>(tw_v);
   auto spectra = static_cast<typename F::elem*>(spectra_v);
   auto kern = bsk_prepare_kernel<F, LOGN>;
   hipError_t e = allow_lds(kern, lds);
   if (e != hipSuccess) return e;
-  const unsigned grid = (unsigned)((poly_count + waves - 1) / waves);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(waves * 64), lds, s, tw, polys, poly_count, spectra,
+  const unsigned grid = (unsigned)((poly_count + groups - 1) / groups);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, tw, polys, poly_count, spectra,
                      F::n_inv(LOGN));
   return hipGetLastError();
 }
@@ -419,7 +444,7 @@ namespace launch {
 
 bool shape_supported(u32 log_n, u32 k) { return log_n >= 9 && log_n <= 11 && (k == 1 || k == 2); }
 
-int waves_per_block(u32 /*log_n*/, u32 k) { return (int)k + 1; }
+int waves_per_block(u32 log_n, u32 k) { return ((int)k + 1) * (log_n >= 11 ? 2 : 1); }
 
 int field_parts(int field) { return field == kFieldFp64 ? FpField::kParts : GlField::kParts; }
 

@@ -88,9 +88,9 @@ TFHE_HD u32 monomial_coeff(const u32* poly, int j, u32 m) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// GGSW (NTT domain) x GLWE external product by a TEAM of K+1 wavefronts (one workgroup).
-//
-// Wave c (c = ctx.wave(), 0..K) owns GLWE polynomial c on the input side and output column c:
+// GGSW (NTT domain) x GLWE external product by a TEAM of K+1 wave groups (one workgroup).  A group
+// is G wavefronts that share one polynomial (G = 1 except for N = 2048); "wave c" below means group
+// c (c = ctx.group(), 0..K), which owns GLWE polynomial c on the input side and output column c:
 //   - it decomposes polynomial c and forward-transforms its `levels` digit rows,
 //   - publishes each spectrum in its LDS transpose buffer (free between two transforms),
 //   - after a workgroup barrier every wave multiplies ALL K+1 published spectra of that level with
@@ -107,15 +107,16 @@ TFHE_HD u32 monomial_coeff(const u32* poly, int j, u32 m) {
 //   out(j, value mod 2^32) is called once per coefficient of output polynomial c.
 // Every wave of the team must call this the same number of times (it contains barriers).
 // ---------------------------------------------------------------------------------------------
-template <class F, int LOGN, int K, class Ctx, class Src, class Out>
+template <class F, int LOGN, int K, int G, class Ctx, class Src, class Out>
 TFHE_HD void external_product_team(const Ctx& c, const PbsParams& P, const typename F::elem* ggsw,
                                    Src src, Out out) {
   typedef typename F::elem elem;
-  constexpr int E = NttShape<LOGN>::kE;
+  constexpr int E = NttShape<LOGN, G>::kE;
+  constexpr int T = NttShape<LOGN, G>::kThreads;  // threads per polynomial
   constexpr int N = 1 << LOGN;
   constexpr int PARTS = F::kParts;
-  const int lane = c.lane();
-  const int me = c.wave();
+  const int lane = c.tid();   // thread index inside my polynomial's group of G waves
+  const int me = c.group();   // polynomial / output column owned by my group
 
   elem accum[PARTS][E];
 #pragma unroll
@@ -128,7 +129,7 @@ TFHE_HD void external_product_team(const Ctx& c, const PbsParams& P, const typen
   // never part of a limb again (every later limb starts at bit >= log_base >= 1).
   u32 v[E];
 #pragma unroll
-  for (int r = 0; r < E; ++r) v[r] = round_value(src(r * 64 + lane), P.ignored_bits);
+  for (int r = 0; r < E; ++r) v[r] = round_value(src(r * T + lane), P.ignored_bits);
 
   // Key tiles of one level for my column, in consumption order: idx = s * PARTS + q, s = source
   // polynomial 0..K, q = part.  A tile is consumed in chunks of CH registers; chunks are staged
@@ -150,7 +151,7 @@ TFHE_HD void external_product_team(const Ctx& c, const PbsParams& P, const typen
     {
       const elem* tile = tile_ptr(level, 0);
 #pragma unroll
-      for (int r = 0; r < CH; ++r) kbuf[0][r] = tile[spectrum_slot<LOGN>(lane, r)];
+      for (int r = 0; r < CH; ++r) kbuf[0][r] = tile[spectrum_slot<LOGN, G>(lane, r)];
     }
     c.compiler_fence();
     {
@@ -165,11 +166,11 @@ TFHE_HD void external_product_team(const Ctx& c, const PbsParams& P, const typen
       }
       // digits are tiny (|d| <= B <= 2^F::kSmallBits, enforced when the context picks the field):
       // the first butterfly stage uses F::mul_small
-      ntt_forward<F, LOGN, true>(c, work);
+      ntt_forward<F, LOGN, G, true>(c, work);
       // publish: element r of lane at [r*64 + lane] (conflict-free 8-byte accesses)
       elem* mine = c.scratch();
 #pragma unroll
-      for (int r = 0; r < E; ++r) mine[r * 64 + lane] = work[r];
+      for (int r = 0; r < E; ++r) mine[r * T + lane] = work[r];
     }
     c.team_sync();
     static_for<0, CHUNKS>([&](auto ci_c) {
@@ -181,12 +182,12 @@ TFHE_HD void external_product_team(const Ctx& c, const PbsParams& P, const typen
         constexpr int nidx = (ci + 1) / (E / CH), nr0 = ((ci + 1) % (E / CH)) * CH;
         const elem* tile = tile_ptr(level, nidx);
 #pragma unroll
-        for (int r = 0; r < CH; ++r) kbuf[nxt][r] = tile[spectrum_slot<LOGN>(lane, nr0 + r)];
+        for (int r = 0; r < CH; ++r) kbuf[nxt][r] = tile[spectrum_slot<LOGN, G>(lane, nr0 + r)];
       }
       const elem* spec = c.scratch_of(s);
       elem d[CH];
 #pragma unroll
-      for (int r = 0; r < CH; ++r) d[r] = spec[(r0 + r) * 64 + lane];
+      for (int r = 0; r < CH; ++r) d[r] = spec[(r0 + r) * T + lane];
       c.compiler_fence();  // keep the next chunk's loads above this chunk's arithmetic
 #pragma unroll
       for (int r = 0; r < CH; ++r)
@@ -199,30 +200,31 @@ TFHE_HD void external_product_team(const Ctx& c, const PbsParams& P, const typen
     constexpr int q = decltype(part_c)::value;
 #pragma unroll
     for (int r = 0; r < E; ++r) accum[q][r] = F::before_inverse(accum[q][r]);
-    ntt_inverse<F, LOGN>(c, accum[q]);
+    ntt_inverse<F, LOGN, G>(c, accum[q]);
   });
 #pragma unroll
   for (int r = 0; r < E; ++r) {
     elem parts[PARTS];
 #pragma unroll
     for (int q = 0; q < PARTS; ++q) parts[q] = accum[q][r];
-    out(r * 64 + lane, F::finish(parts));
+    out(r * T + lane, F::finish(parts));
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// Blind rotation of ONE LWE sample (bootstrapping.rs:67-105) by a team of K+1 waves.  Wave c keeps
-// polynomial c of the accumulator in its private LDS array c.acc() (N u32, natural order) for all
-// n iterations; on return it holds polynomial c of the final GLWE accumulator.
+// Blind rotation of ONE LWE sample (bootstrapping.rs:67-105) by a team of K+1 groups of G waves.
+// Group c keeps polynomial c of the accumulator in its LDS array c.acc() (N u32, natural order)
+// for all n iterations; on return it holds polynomial c of the final GLWE accumulator.
 // ---------------------------------------------------------------------------------------------
-template <class F, int LOGN, int K, class Ctx>
+template <class F, int LOGN, int K, int G, class Ctx>
 TFHE_HD void blind_rotate_team(const Ctx& c, const PbsParams& P, const u32* lwe /* n+1 */,
                                const u32* tv /* N, un-encoded */,
                                const typename F::elem* bsk /* prepared */) {
-  constexpr int E = NttShape<LOGN>::kE;
+  constexpr int E = NttShape<LOGN, G>::kE;
+  constexpr int T = NttShape<LOGN, G>::kThreads;
   constexpr int N = 1 << LOGN;
-  const int lane = c.lane();
-  const int me = c.wave();
+  const int lane = c.tid();
+  const int me = c.group();
   u32* acc = c.acc();
 
   // acc = X^{-b~} * (0, ..., 0, tv << tv_shift): only the body polynomial (wave K) is non-zero
@@ -233,7 +235,7 @@ TFHE_HD void blind_rotate_team(const Ctx& c, const PbsParams& P, const u32* lwe 
     const u32 flip = (m >> LOGN) & 1u;
 #pragma unroll
     for (int r = 0; r < E; ++r) {
-      const int j = r * 64 + lane;
+      const int j = r * T + lane;
       u32 val = 0;
       if (me == K) {
         const u32 t = tv[(j - deg) & (N - 1)] << P.tv_shift;
@@ -241,7 +243,7 @@ TFHE_HD void blind_rotate_team(const Ctx& c, const PbsParams& P, const u32* lwe 
       }
       acc[j] = val;
     }
-    c.sync();
+    c.poly_sync();
   }
 
   const size_t ggsw_words = (size_t)(K + 1) * P.levels * (K + 1) * F::kParts * N;
@@ -254,24 +256,25 @@ TFHE_HD void blind_rotate_team(const Ctx& c, const PbsParams& P, const u32* lwe 
     auto src = [&](int j) -> u32 { return monomial_coeff<LOGN>(acc, j, a_tilde) - acc[j]; };
     // all rotated reads of acc happen before the first inverse transform: in-place update is safe
     auto out = [&](int j, u32 value) { acc[j] += value; };
-    external_product_team<F, LOGN, K>(c, P, bsk + (size_t)i * ggsw_words, src, out);
-    c.sync();
+    external_product_team<F, LOGN, K, G>(c, P, bsk + (size_t)i * ggsw_words, src, out);
+    c.poly_sync();
   }
 }
 
 // sample_extract at index 0 (bootstrapping.rs:122-156): wave c < K writes the N mask words of its
 // polynomial, wave K writes the body word
-template <int LOGN, int K, class Ctx>
+template <int LOGN, int K, int G, class Ctx>
 TFHE_HD void sample_extract_team(const Ctx& c, u32* out /* K*N + 1 */) {
-  constexpr int E = NttShape<LOGN>::kE;
+  constexpr int E = NttShape<LOGN, G>::kE;
+  constexpr int T = NttShape<LOGN, G>::kThreads;
   constexpr int N = 1 << LOGN;
-  const int lane = c.lane();
-  const int me = c.wave();
+  const int lane = c.tid();
+  const int me = c.group();
   const u32* acc = c.acc();
   if (me < K) {
 #pragma unroll
     for (int r = 0; r < E; ++r) {
-      const int x = r * 64 + lane;
+      const int x = r * T + lane;
       out[me * N + x] = (x == 0) ? acc[0] : (0u - acc[N - x]);
     }
   } else if (lane == 0) {
@@ -281,21 +284,23 @@ TFHE_HD void sample_extract_team(const Ctx& c, u32* out /* K*N + 1 */) {
 
 // Forward NTT of one u32 polynomial of the bootstrapping key into the prepared layout,
 // pre-scaled by N^-1.
-template <class F, int LOGN, class Ctx>
+template <class F, int LOGN, int G, class Ctx>
 TFHE_HD void bsk_prepare_wave(const Ctx& c, const u32* poly, typename F::elem* spec /* [kParts][N] */,
                               typename F::elem n_inv) {
   typedef typename F::elem elem;
-  constexpr int E = NttShape<LOGN>::kE;
+  constexpr int E = NttShape<LOGN, G>::kE;
+  constexpr int T = NttShape<LOGN, G>::kThreads;
   constexpr int N = 1 << LOGN;
-  const int lane = c.lane();
+  const int lane = c.tid();
 #pragma unroll 1
   for (int part = 0; part < F::kParts; ++part) {
     elem x[E];
 #pragma unroll
-    for (int r = 0; r < E; ++r) x[r] = F::from_key_word(poly[r * 64 + lane], part);
-    ntt_forward<F, LOGN>(c, x);
+    for (int r = 0; r < E; ++r) x[r] = F::from_key_word(poly[r * T + lane], part);
+    ntt_forward<F, LOGN, G>(c, x);
 #pragma unroll
-    for (int r = 0; r < E; ++r) spec[(size_t)part * N + spectrum_slot<LOGN>(lane, r)] = F::mul(x[r], n_inv);
+    for (int r = 0; r < E; ++r)
+      spec[(size_t)part * N + spectrum_slot<LOGN, G>(lane, r)] = F::mul(x[r], n_inv);
   }
 }
 

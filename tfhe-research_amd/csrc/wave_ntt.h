@@ -1,6 +1,9 @@
-// wave_ntt.h -- exact negacyclic NTT of one polynomial held by ONE 64-lane wavefront.
+// wave_ntt.h -- exact negacyclic NTT of one polynomial held by a GROUP of G 64-lane wavefronts
+// (G = 1: one wave per polynomial, no barrier inside a transform; G = 2 for N = 2048 so that a lane
+// still holds only 16 elements per array).
 //
-// N = 2^LOGN coefficients live in E = N/64 registers per lane (u64 each).  The transform is the
+// N = 2^LOGN coefficients live in E = N/(64 G) registers per lane (8 bytes each); below "tid" is the
+// thread index inside the group (0 .. 64G-1) and TB = log2(64 G).  The transform is the
 // merged-psi Cooley-Tukey NTT (natural order in, bit-reversed order out) and its Gentleman-Sande
 // inverse, executed as three "register passes".  A pass owns a window of e = log2(E) index bits:
 // in window [LO, LO+e) a lane holds the E indices that differ only in those bits,
@@ -10,10 +13,12 @@
 // makes all ds_write_b64 / ds_read_b64 of the transposes bank-conflict free on gfx950
 // (tools/ntt_model.py proves layout and conflict-freedom for LOGN = 9, 10, 11).
 //
-//   forward : window [6,6+e) (j = r*64 + lane, coalesced) -> [6-e,6) -> [0,e)
-//   inverse : the mirror image, ends in [6,6+e) again.
+//   forward : window [TB,TB+e) (j = r*64G + tid, coalesced) -> [TB-e,TB) -> [0,e)
+//   inverse : the mirror image, ends in [TB,TB+e) again.
+// (in the formulas above read "lane" as tid and 6 as TB.)  For G > 1 the transposes cross waves, so
+// Ctx::poly_sync() is a workgroup barrier there; for G = 1 it only fences the compiler.
 //
-// In window [0,e) position pos = lane*E + r of the bit-reversed-order spectrum sits in register r.
+// In window [0,e) position pos = tid*E + r of the bit-reversed-order spectrum sits in register r.
 // The inverse is NOT scaled by N^-1: the bootstrapping key is pre-scaled instead (bsk_prepare).
 //
 // One twiddle table serves both directions: psi_rev[k] = psi^bitrev(k), and
@@ -30,69 +35,77 @@
 
 namespace tfhe {
 
-template <int LOGN>
+template <int LOGN, int G = 1>
 struct NttShape {
-  static_assert(LOGN >= 9 && LOGN <= 11, "one wavefront per polynomial supports N = 512..2048");
+  static_assert(G == 1 || G == 2 || G == 4, "waves per polynomial");
   static constexpr int kLogN = LOGN;
   static constexpr int kN = 1 << LOGN;
-  static constexpr int kEBits = LOGN - 6;
+  static constexpr int kG = G;
+  static constexpr int kThreads = 64 * G;
+  static constexpr int kTBits = (G == 1) ? 6 : (G == 2) ? 7 : 8;
+  static constexpr int kEBits = LOGN - kTBits;
   static constexpr int kE = 1 << kEBits;
+  static_assert(kEBits >= 3 && kEBits <= 5, "8..32 elements per lane");
+  static_assert(kTBits <= 2 * kEBits, "three register passes must cover all index bits");
   // window lows of the three passes (forward order)
-  static constexpr int kLo1 = 6;
-  static constexpr int kLo2 = 6 - kEBits;
+  static constexpr int kLo1 = kTBits;
+  static constexpr int kLo2 = kTBits - kEBits;
   static constexpr int kLo3 = 0;
 };
 
-// XOR swizzle of the transpose buffer (element = u64).  See tools/ntt_model.py::conflicts.
-template <int LOGN>
+// XOR swizzle of the transpose buffer (element = 8 bytes).  Each one makes every ds_write_b64 and
+// ds_read_b64 of both transposes, in both directions, bank-conflict free (tools/ntt_model.py).
+template <int LOGN, int G>
 TFHE_HD int ntt_swizzle(int j) {
-  if (LOGN == 10) return j ^ ((j >> 4) & 31);
-  if (LOGN == 9) return j ^ ((j >> 3) & 7) ^ (((j >> 6) & 3) << 3);
-  return j ^ ((j >> 5) & 31);
+  if (G == 1 && LOGN == 10) return j ^ ((j >> 4) & 31);
+  if (G == 1 && LOGN == 9) return j ^ ((j >> 3) & 7) ^ (((j >> 6) & 3) << 3);
+  if (G == 1 && LOGN == 11) return j ^ ((j >> 5) & 31);
+  if (G == 2 && LOGN == 11) return j ^ ((j >> 1) & 7) ^ ((j >> 4) & 31);
+  return j;  // correct for any shape, just not conflict-free
 }
 
-// element index held in register r of `lane` for window [LO, LO+e)
-template <int LOGN, int LO>
-TFHE_HD int ntt_index(int lane, int r) {
-  constexpr int e = NttShape<LOGN>::kEBits;
-  return ((lane >> LO) << (LO + e)) | (r << LO) | (lane & ((1 << LO) - 1));
+// element index held in register r of thread `tid` for window [LO, LO+e)
+template <int LOGN, int G, int LO>
+TFHE_HD int ntt_index(int tid, int r) {
+  constexpr int e = NttShape<LOGN, G>::kEBits;
+  return ((tid >> LO) << (LO + e)) | (r << LO) | (tid & ((1 << LO) - 1));
 }
 
-// memory position (in u64 elements) of spectrum register r of `lane` inside one NTT-domain
+// memory position (in elements) of spectrum register r of thread `tid` inside one NTT-domain
 // polynomial of the prepared bootstrapping key: pairs of registers are interleaved so that one
-// global_load_dwordx4 per lane reads 64 x 16 B = 1 KiB contiguous.
-template <int LOGN>
-TFHE_HD int spectrum_slot(int lane, int r) {
-  return (r >> 1) * 128 + lane * 2 + (r & 1);
+// global_load_dwordx4 per lane reads 64 x 16 B = 1 KiB contiguous per wave.
+template <int LOGN, int G>
+TFHE_HD int spectrum_slot(int tid, int r) {
+  return (r >> 1) * (2 * NttShape<LOGN, G>::kThreads) + tid * 2 + (r & 1);
 }
 
-template <class F, int LOGN, int LO_FROM, int LO_TO, class Ctx>
-TFHE_HD void ntt_transpose(const Ctx& c, typename F::elem (&x)[NttShape<LOGN>::kE]) {
-  constexpr int E = NttShape<LOGN>::kE;
+template <class F, int LOGN, int G, int LO_FROM, int LO_TO, class Ctx>
+TFHE_HD void ntt_transpose(const Ctx& c, typename F::elem (&x)[NttShape<LOGN, G>::kE]) {
+  constexpr int E = NttShape<LOGN, G>::kE;
   typename F::elem* buf = c.scratch();
-  const int lane = c.lane();
+  const int tid = c.tid();
 #pragma unroll
-  for (int r = 0; r < E; ++r) buf[ntt_swizzle<LOGN>(ntt_index<LOGN, LO_FROM>(lane, r))] = x[r];
-  c.sync();
+  for (int r = 0; r < E; ++r) buf[ntt_swizzle<LOGN, G>(ntt_index<LOGN, G, LO_FROM>(tid, r))] = x[r];
+  c.poly_sync();
 #pragma unroll
-  for (int r = 0; r < E; ++r) x[r] = buf[ntt_swizzle<LOGN>(ntt_index<LOGN, LO_TO>(lane, r))];
-  c.sync();
+  for (int r = 0; r < E; ++r) x[r] = buf[ntt_swizzle<LOGN, G>(ntt_index<LOGN, G, LO_TO>(tid, r))];
+  c.poly_sync();
 }
 
 // forward stages on bits BHI..BLO (descending) of window [LO, LO+e).  SMALL_FIRST: the inputs of
 // the first stage handled here are small integers (gadget digits), so its twiddle products may
 // use F::mul_small (exact without reduction in the fp64 field).
-template <class F, int LOGN, int LO, int BHI, int BLO, bool SMALL_FIRST, class Ctx>
-TFHE_HD void ntt_pass_forward(const Ctx& c, typename F::elem (&x)[NttShape<LOGN>::kE]) {
+template <class F, int LOGN, int G, int LO, int BHI, int BLO, bool SMALL_FIRST, class Ctx>
+TFHE_HD void ntt_pass_forward(const Ctx& c, typename F::elem (&x)[NttShape<LOGN, G>::kE]) {
   typedef typename F::elem elem;
-  constexpr int E = NttShape<LOGN>::kE;
-  constexpr int e = NttShape<LOGN>::kEBits;
+  constexpr int E = NttShape<LOGN, G>::kE;
+  constexpr int e = NttShape<LOGN, G>::kEBits;
   const elem* tw = c.twiddles();
-  const int hi = c.lane() >> LO;
+  const int hi = c.tid() >> LO;
 #pragma unroll
   for (int b = BHI; b >= BLO; --b) {
     const int rb = b - LO;
-    const int m = NttShape<LOGN>::kN >> (b + 1);
+    const int m = NttShape<LOGN, G>::kN >> (b + 1);
     const int base = m + (hi << (LO + e - b - 1));
 #pragma unroll
     for (int r0 = 0; r0 < E; ++r0) {
@@ -108,17 +121,17 @@ TFHE_HD void ntt_pass_forward(const Ctx& c, typename F::elem (&x)[NttShape<LOGN>
 }
 
 // inverse stages on bits BLO..BHI (ascending) of window [LO, LO+e)
-template <class F, int LOGN, int LO, int BHI, int BLO, class Ctx>
-TFHE_HD void ntt_pass_inverse(const Ctx& c, typename F::elem (&x)[NttShape<LOGN>::kE]) {
+template <class F, int LOGN, int G, int LO, int BHI, int BLO, class Ctx>
+TFHE_HD void ntt_pass_inverse(const Ctx& c, typename F::elem (&x)[NttShape<LOGN, G>::kE]) {
   typedef typename F::elem elem;
-  constexpr int E = NttShape<LOGN>::kE;
-  constexpr int e = NttShape<LOGN>::kEBits;
+  constexpr int E = NttShape<LOGN, G>::kE;
+  constexpr int e = NttShape<LOGN, G>::kEBits;
   const elem* tw = c.twiddles();
-  const int hi = c.lane() >> LO;
+  const int hi = c.tid() >> LO;
 #pragma unroll
   for (int b = BLO; b <= BHI; ++b) {
     const int rb = b - LO;
-    const int h = NttShape<LOGN>::kN >> (b + 1);
+    const int h = NttShape<LOGN, G>::kN >> (b + 1);
     // psi^-bitrev(h+i) = -psi_rev[2h-1-i]
     const int top = 2 * h - 1 - (hi << (LO + e - b - 1));
 #pragma unroll
@@ -134,27 +147,27 @@ TFHE_HD void ntt_pass_inverse(const Ctx& c, typename F::elem (&x)[NttShape<LOGN>
   }
 }
 
-// in: x[r] = a[r*64 + lane] (canonical field elements).  out: x[r] = A_bitrev[lane*E + r].
+// in: x[r] = a[r*64G + tid].  out: x[r] = A_bitrev[tid*E + r].
 // SMALL_INPUT: every |x[r]| <= 2^F::kSmallBits on entry (gadget digits).
-template <class F, int LOGN, bool SMALL_INPUT = false, class Ctx>
-TFHE_HD void ntt_forward(const Ctx& c, typename F::elem (&x)[NttShape<LOGN>::kE]) {
-  using S = NttShape<LOGN>;
-  ntt_pass_forward<F, LOGN, S::kLo1, LOGN - 1, 6, SMALL_INPUT>(c, x);
-  ntt_transpose<F, LOGN, S::kLo1, S::kLo2>(c, x);
-  ntt_pass_forward<F, LOGN, S::kLo2, 5, S::kLo2, false>(c, x);
-  ntt_transpose<F, LOGN, S::kLo2, S::kLo3>(c, x);
-  ntt_pass_forward<F, LOGN, S::kLo3, S::kLo2 - 1, 0, false>(c, x);
+template <class F, int LOGN, int G, bool SMALL_INPUT = false, class Ctx>
+TFHE_HD void ntt_forward(const Ctx& c, typename F::elem (&x)[NttShape<LOGN, G>::kE]) {
+  using S = NttShape<LOGN, G>;
+  ntt_pass_forward<F, LOGN, G, S::kLo1, LOGN - 1, S::kTBits, SMALL_INPUT>(c, x);
+  ntt_transpose<F, LOGN, G, S::kLo1, S::kLo2>(c, x);
+  ntt_pass_forward<F, LOGN, G, S::kLo2, S::kTBits - 1, S::kLo2, false>(c, x);
+  ntt_transpose<F, LOGN, G, S::kLo2, S::kLo3>(c, x);
+  ntt_pass_forward<F, LOGN, G, S::kLo3, S::kLo2 - 1, 0, false>(c, x);
 }
 
-// in: x[r] = A_bitrev[lane*E + r].  out: x[r] = N * a[r*64 + lane] (unscaled inverse).
-template <class F, int LOGN, class Ctx>
-TFHE_HD void ntt_inverse(const Ctx& c, typename F::elem (&x)[NttShape<LOGN>::kE]) {
-  using S = NttShape<LOGN>;
-  ntt_pass_inverse<F, LOGN, S::kLo3, S::kLo2 - 1, 0>(c, x);
-  ntt_transpose<F, LOGN, S::kLo3, S::kLo2>(c, x);
-  ntt_pass_inverse<F, LOGN, S::kLo2, 5, S::kLo2>(c, x);
-  ntt_transpose<F, LOGN, S::kLo2, S::kLo1>(c, x);
-  ntt_pass_inverse<F, LOGN, S::kLo1, LOGN - 1, 6>(c, x);
+// in: x[r] = A_bitrev[tid*E + r].  out: x[r] = N * a[r*64G + tid] (unscaled inverse).
+template <class F, int LOGN, int G, class Ctx>
+TFHE_HD void ntt_inverse(const Ctx& c, typename F::elem (&x)[NttShape<LOGN, G>::kE]) {
+  using S = NttShape<LOGN, G>;
+  ntt_pass_inverse<F, LOGN, G, S::kLo3, S::kLo2 - 1, 0>(c, x);
+  ntt_transpose<F, LOGN, G, S::kLo3, S::kLo2>(c, x);
+  ntt_pass_inverse<F, LOGN, G, S::kLo2, S::kTBits - 1, S::kLo2>(c, x);
+  ntt_transpose<F, LOGN, G, S::kLo2, S::kLo1>(c, x);
+  ntt_pass_inverse<F, LOGN, G, S::kLo1, LOGN - 1, S::kTBits>(c, x);
 }
 
 }  // namespace tfhe

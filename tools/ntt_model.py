@@ -235,6 +235,45 @@ def selfcheck(logn, seed=1):
     return conflicts(logn)
 
 
+def conflicts_grouped(logn=11, g=2):
+    """Same bank-conflict evaluation for G waves per polynomial (tid has 6 + log2(g) bits); the
+    swizzle is the one in wave_ntt.h::ntt_swizzle<11, 2>."""
+    tb = 6 + (g.bit_length() - 1)
+    e = logn - tb
+    E = 1 << e
+
+    def swz(j):
+        return j ^ ((j >> 1) & 7) ^ ((j >> 4) & 31)
+
+    def index(tid, r, lo):
+        return ((tid >> lo) << (lo + e)) | (r << lo) | (tid & ((1 << lo) - 1))
+
+    assert sorted(swz(j) for j in range(1 << logn)) == list(range(1 << logn))
+    los = [tb, tb - e, 0]
+    out = {}
+    for wlo, rlo in [(los[0], los[1]), (los[1], los[2]), (los[2], los[1]), (los[1], los[0])]:
+        ww = wr = 0
+        for wave in range(g):
+            for r in range(E):
+                for grp in range(4):
+                    banks = {}
+                    for l in range(grp * 16, grp * 16 + 16):
+                        a = swz(index(wave * 64 + l, r, wlo))
+                        for d in (0, 1):
+                            banks.setdefault((a * 2 + d) % 32, set()).add(a)
+                    ww = max(ww, max(len(s) for s in banks.values()))
+                for grp in range(2):
+                    banks = {}
+                    for l in range(grp * 32, grp * 32 + 32):
+                        a = swz(index(wave * 64 + l, r, rlo))
+                        for d in (0, 1):
+                            banks.setdefault((a * 2 + d) % 64, set()).add(a)
+                    wr = max(wr, max(len(s) for s in banks.values()))
+        out[(wlo, rlo)] = (ww, wr)
+    return out
+
+
 if __name__ == "__main__":
     for logn in (9, 10, 11):
         print(logn, selfcheck(logn))
+    print("11 x2 waves", conflicts_grouped())
