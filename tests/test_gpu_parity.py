@@ -296,3 +296,50 @@ def test_batch_4096_properties_cfg2(oracle):
     assert np.array_equal(out.reshape(64, 64, -1), np.broadcast_to(base, (64, 64, p.n + 1)))
     for b in (5, 40):
         assert np.array_equal(base[b], oracle.bootstrap(p, lwe[b], bsk, ksk, tv)), b
+
+
+def test_device_entry_points_are_graph_capturable(oracle):
+    """The `_device` entry points promise no allocation and no synchronisation once the workspace is
+    reserved: capture a whole bootstrap (blind rotation + key switch) into a HIP graph on a torch
+    stream, replay it on new inputs, and compare with the eager result and the oracle."""
+    import torch
+    p = oracle.Params(1, 10, 6, oracle.Decomposer(7, 3))
+    lwe, bsk, ksk, tv = oracle.synthetic_inputs(p, 16, cfg_index=11)
+    m = pkg()
+    dev = torch.device("cuda", 0)
+    with m.Context(to_pkg_params(p)) as ctx:
+        ctx.load_bootstrapping_key(bsk, ksk)
+        ctx.reserve(16)
+        lwe_d = torch.from_numpy(lwe.view(np.int32).copy()).to(dev)
+        tv_d = torch.from_numpy(tv.view(np.int32).copy()).to(dev)
+        out_d = torch.empty_like(lwe_d)
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            ctx.use_torch_stream()
+            ctx.bootstrap(lwe_d, tv_d, out=out_d)  # warm-up outside the capture (one-time kernel attributes)
+            side.synchronize()
+            eager = out_d.cpu().numpy().view(np.uint32).copy()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                ctx.bootstrap(lwe_d, tv_d, out=out_d)
+            # replay on different inputs written into the captured buffers
+            lwe2 = np.roll(lwe, 3, axis=0)
+            lwe_d.copy_(torch.from_numpy(lwe2.view(np.int32).copy()))
+            graph.replay()
+            side.synchronize()
+            replayed = out_d.cpu().numpy().view(np.uint32).copy()
+        ctx.set_stream(None)
+    assert np.array_equal(replayed, np.roll(eager, 3, axis=0))
+    assert np.array_equal(eager[2], oracle.bootstrap(p, lwe[2], bsk, ksk, tv))
+
+
+def test_batch_edge_cases(oracle, contexts):
+    """batch of 1, odd batches, and the empty batch (refused with a status, never a crash)."""
+    p, ctx, lwe, bsk, ksk, tv = contexts("cfg2_small", "auto")
+    m = pkg()
+    full = ctx.bootstrap(lwe, tv)
+    for size in (1, 2, 3, 7):
+        assert np.array_equal(ctx.bootstrap(lwe[:size], tv), full[:size])
+    with pytest.raises(m.TfheError) as e:
+        ctx.bootstrap(np.zeros((0, p.n + 1), dtype=np.uint32), tv)
+    assert e.value.status == 5

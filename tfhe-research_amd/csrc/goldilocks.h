@@ -34,9 +34,6 @@ TFHE_HD u64 sub(u64 a, u64 b) {
   return d - ((a < b) ? EPS : 0ull);  // borrow: add p == subtract EPS (mod 2^64)
 }
 
-TFHE_HD u64 canon(u64 a) { return a >= P ? a - P : a; }
-TFHE_HD u64 neg(u64 a) { return a ? P - a : 0ull; }
-
 // x = (hi, lo) 128-bit -> canonical residue.  2^64 = EPS, 2^96 = -1 (mod p).
 TFHE_HD u64 reduce128(u64 lo, u64 hi) {
   u32 x2 = (u32)hi, x3 = (u32)(hi >> 32);
@@ -68,10 +65,9 @@ TFHE_HD u64 from_i32(u32 d) {
   return ((i32)d < 0) ? P - (u64)(u32)(0u - d) : (u64)d;
 }
 
-// centred lift of a weakly reduced value whose true integer |x| < 2^62, reduced mod 2^32.
-// x >= 0: v = x (top bit clear) -> lo32(v).  x < 0: v = x + p (or x + 2p - 2^64... never needed)
-// has its top bit set and p = 1 (mod 2^32) -> lo32(v) - 1.  A non-canonical v in [p, 2^64) means
-// x = v - p >= 0 small, top bit set as well, and again lo32(v) - 1.
+// centred lift of a residue v whose true integer x satisfies |x| < 2^62, reduced mod 2^32.
+// x >= 0: v = x (top bit clear) -> lo32(v).  x < 0: v = x + p has its top bit set and
+// p = 1 (mod 2^32) -> lo32(v) - 1.
 TFHE_HD u32 lift_mod_2_32(u64 v) { return (u32)v - (u32)(v >> 63); }
 
 TFHE_HD u64 pow(u64 base, u64 e) {
