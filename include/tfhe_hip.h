@@ -75,7 +75,7 @@ int tfhe_params_validate(const tfhe_params *params);
 /* Exact-NTT backends.  Both give identical bits; they differ in speed and in the parameter sets
  * they can lift exactly (checked at context creation, TFHE_ERR_EXACTNESS otherwise):
  *   FP64       42-bit prime, fp64 arithmetic, key split into 16-bit halves; needs
- *              (k+1)*l * N * B * 2^15 < 2^40.9 and log_base <= 11
+ *              (k+1)*l * N * B * 2^15 < 2^40.9 and log_base <= 9
  *   GOLDILOCKS p = 2^64 - 2^32 + 1, u64 arithmetic; needs (k+1)*l * N * B * 2^32 < 2^62
  *   AUTO       FP64 when its bound holds, else GOLDILOCKS (env TFHE_HIP_BACKEND=fp64|goldilocks
  *              overrides AUTO). */
@@ -166,6 +166,16 @@ int tfhe_switch_modulus(tfhe_context *ctx, const uint32_t *values, size_t count,
 /* &GlweCiphertext * &Monomial: glwe.rs:20-34, one monomial index per ciphertext */
 int tfhe_glwe_mul_monomial_batch(tfhe_context *ctx, const uint32_t *glwe_in, size_t batch,
                                  const int64_t *monomial_index, uint32_t *glwe_out);
+
+/* ---- lwe.rs ------------------------------------------------------------------------------- */
+/* out = c0*ct0 + c1*ct1 over [batch][n+1] words (wrapping): `&a + &b` is (1, 1) (lwe.rs:9-15),
+ * `&a * s` is (s, 0) with ct1 = NULL (lwe.rs:17-23), the gate input 2*ct1 + ct0 is (1, 2)
+ * (boolean.rs:18).  `words_per_ct` lets the same call serve any LWE dimension. */
+int tfhe_lwe_linear_batch(tfhe_context *ctx, uint32_t c0, const uint32_t *ct0, uint32_t c1,
+                          const uint32_t *ct1, size_t batch, size_t words_per_ct, uint32_t *out);
+int tfhe_lwe_linear_batch_device(tfhe_context *ctx, uint32_t c0, const uint32_t *ct0, uint32_t c1,
+                                 const uint32_t *ct1, size_t batch, size_t words_per_ct,
+                                 uint32_t *out);
 
 /* ---- test_vector.rs / boolean.rs ---------------------------------------------------------- */
 /* construct_test_from_lut: test_vector.rs:38-67 (host-side, no GPU).  out [N] */

@@ -53,7 +53,7 @@ void run_team(int logn, int groups, int g, const std::function<void(const HostWa
   team.g = g;
   team.scratch.resize((size_t)groups * team.n);
   team.acc.resize((size_t)groups * team.n);
-  team.tw.resize(team.n);
+  team.tw.resize(ntt_twiddle_words(team.n));
   F::fill_twiddles(logn, team.tw.data());
   const int waves = groups * g;
   pthread_barrier_init(&team.team_bar, nullptr, waves * kWave);

@@ -428,6 +428,17 @@ class Context:
                                                        idx.ctypes.data_as(C.POINTER(C.c_int64)), _hp(res)))
         return res
 
+    def lwe_linear(self, c0: int, ct0, c1: int = 0, ct1=None) -> np.ndarray:
+        """c0*ct0 + c1*ct1 (wrapping): LweCiphertext Add / Mul<u32>, lwe.rs:9-23."""
+        a = _np(ct0)
+        rows = a.reshape(-1, a.shape[-1])
+        b = _np(ct1).reshape(rows.shape) if ct1 is not None else None
+        res = np.zeros_like(rows)
+        self._check(lib().tfhe_lwe_linear_batch(self._h, C.c_uint32(c0 & 0xFFFFFFFF), _hp(rows),
+                                                C.c_uint32(c1 & 0xFFFFFFFF), _hp(b) if b is not None else None,
+                                                C.c_size_t(rows.shape[0]), C.c_size_t(rows.shape[1]), _hp(res)))
+        return res.reshape(a.shape)
+
     def gate(self, truth, ct0, ct1, out=None):
         """and()/or(): boolean.rs:9-53 generalised: bootstrap(2*ct1 + ct0) with the closure's TV."""
         p = self.params

@@ -203,11 +203,11 @@ double convolution_bits(const tfhe_params* p, double key_bits) {
 
 template <class F>
 hipError_t upload_twiddles(tfhe_context* ctx) {
-  std::vector<typename F::elem> tw(ctx->N);
+  std::vector<typename F::elem> tw(ntt_twiddle_words((int)ctx->N));
   F::fill_twiddles((int)ctx->params.glwe_poly_degree, tw.data());
-  hipError_t e = hipMalloc(&ctx->d_tw, ctx->N * sizeof(typename F::elem));
+  hipError_t e = hipMalloc(&ctx->d_tw, tw.size() * sizeof(typename F::elem));
   if (e != hipSuccess) return e;
-  return hipMemcpy(ctx->d_tw, tw.data(), ctx->N * sizeof(typename F::elem), hipMemcpyHostToDevice);
+  return hipMemcpy(ctx->d_tw, tw.data(), tw.size() * sizeof(typename F::elem), hipMemcpyHostToDevice);
 }
 
 }  // namespace
@@ -720,6 +720,36 @@ int tfhe_glwe_mul_monomial_batch(tfhe_context* ctx, const uint32_t* glwe_in, siz
   return TFHE_OK;
 }
 
+// ---------------------------------------------------------------------------------- lwe.rs
+int tfhe_lwe_linear_batch_device(tfhe_context* ctx, uint32_t c0, const uint32_t* ct0, uint32_t c1,
+                                 const uint32_t* ct1, size_t batch, size_t words_per_ct, uint32_t* out) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  if (!ct0 || !out || batch == 0 || words_per_ct == 0 || (c1 != 0 && !ct1))
+    return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer / empty batch");
+  HIP_TRY(ctx, launch::lwe_linear(ctx->stream, c0, ct0, c1, c1 ? ct1 : nullptr, batch * words_per_ct, out));
+  return TFHE_OK;
+}
+
+int tfhe_lwe_linear_batch(tfhe_context* ctx, uint32_t c0, const uint32_t* ct0, uint32_t c1,
+                          const uint32_t* ct1, size_t batch, size_t words_per_ct, uint32_t* out) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  if (!ct0 || !out || batch == 0 || words_per_ct == 0 || (c1 != 0 && !ct1))
+    return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer / empty batch");
+  const size_t words = batch * words_per_ct;
+  if ((st = ensure_misc(ctx, 3 * words * sizeof(u32)))) return st;
+  u32* d0 = reinterpret_cast<u32*>(ctx->d_misc);
+  u32* d1 = d0 + words;
+  u32* dout = d1 + words;
+  HIP_TRY(ctx, hipMemcpyAsync(d0, ct0, words * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+  if (c1) HIP_TRY(ctx, hipMemcpyAsync(d1, ct1, words * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+  if ((st = tfhe_lwe_linear_batch_device(ctx, c0, d0, c1, c1 ? d1 : nullptr, batch, words_per_ct, dout))) return st;
+  HIP_TRY(ctx, hipMemcpyAsync(out, dout, words * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return TFHE_OK;
+}
+
 // ---------------------------------------------------------------------------------- test vectors / gates
 int tfhe_construct_test_from_lut(const tfhe_params* params, const uint32_t* lut, size_t lut_len, uint32_t* out) {
   if (!params || !lut || !out) return TFHE_ERR_INVALID_ARGUMENT;
@@ -756,7 +786,7 @@ int tfhe_gate_batch_device(tfhe_context* ctx, const uint32_t truth[4], const uin
     HIP_TRY(ctx, hipMemcpy(ctx->d_tv_gate, tv.data(), ctx->N * sizeof(u32), hipMemcpyHostToDevice));
     std::memcpy(ctx->gate_truth, truth, sizeof(ctx->gate_truth));
   }
-  HIP_TRY(ctx, launch::lwe_gate_input(ctx->stream, ct0, ct1, words, ctx->d_lwe_in2));
+  HIP_TRY(ctx, launch::lwe_linear(ctx->stream, 1u, ct0, 2u, ct1, words, ctx->d_lwe_in2));  // 2*ct1 + ct0
   return enqueue_bootstrap(ctx, ctx->d_lwe_in2, batch, ctx->d_tv_gate, 1, ctx->d_lwe_big, lwe_out);
 }
 

@@ -16,6 +16,8 @@ struct GlField {
   TFHE_HD static elem mul(elem a, elem w) { return gl::mul(a, w); }
   static constexpr int kSmallBits = 31;  // mul_small is the full product here: any digit qualifies
   TFHE_HD static elem mul_small(elem a, elem w) { return gl::mul(a, w); }
+  static constexpr bool kFuseFirstTwo = false;  // canonical u64 arithmetic gains nothing from it
+  TFHE_HD static void radix4_small(elem&, elem&, elem&, elem&, elem, elem, elem, elem, elem) {}
   // gadget digit (wrapped u32 holding a small signed integer) -> field element
   TFHE_HD static elem from_digit(u32 d) { return gl::from_i32(d); }
   // key word -> field element of spectrum `part`
@@ -26,6 +28,7 @@ struct GlField {
   TFHE_HD static u32 finish(const elem (&parts)[kParts]) { return gl::lift_mod_2_32(parts[0]); }
 
   // ---- host-side constants ----
+  // out: n + 2 elements (wave_ntt.h::ntt_twiddle_words)
   static inline void fill_twiddles(int logn, elem* out) {
     const int n = 1 << logn;
     const u64 psi = gl::root_of_unity(logn + 1);
@@ -36,6 +39,8 @@ struct GlField {
       out[rev] = pw;  // psi_rev[j] = psi^bitrev(j)
       pw = gl::mul(pw, psi);
     }
+    out[n] = gl::mul(out[1], out[2]);
+    out[n + 1] = gl::mul(out[1], out[3]);
   }
   static inline elem n_inv(int logn) { return gl::inv((u64)1 << logn); }
   // log2 of the largest |integer convolution value| this field lifts exactly

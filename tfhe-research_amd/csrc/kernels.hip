@@ -68,7 +68,8 @@ struct TeamCfg {
   static constexpr int kWaves = (K + 1) * G;
   static constexpr int kThreads = kWaves * 64;
   static constexpr unsigned kGroupLds = (unsigned)N * 8u + (unsigned)N * 4u;
-  static constexpr size_t kLds = (size_t)N * 8 + (size_t)(K + 1) * kGroupLds;
+  static constexpr size_t kTwBytes = (size_t)ntt_twiddle_words(N) * 8;  // multiple of 16
+  static constexpr size_t kLds = kTwBytes + (size_t)(K + 1) * kGroupLds;
   static constexpr int kMinWavesGl = TFHE_WAVES_PER_SIMD_GL;
   static constexpr int kMinWavesFp = TFHE_WAVES_PER_SIMD_FP;
 };
@@ -79,12 +80,12 @@ __device__ __forceinline__ DeviceWave<typename F::elem, GroupOf<LOGN>::value> ma
   typedef typename F::elem elem;
   using C = TeamCfg<LOGN, K>;
   elem* tw = reinterpret_cast<elem*>(smem);
-  for (int i = threadIdx.x; i < C::N; i += blockDim.x) tw[i] = tw_global[i];
+  for (int i = threadIdx.x; i < ntt_twiddle_words(C::N); i += blockDim.x) tw[i] = tw_global[i];
   __syncthreads();
   DeviceWave<elem, C::G> w;
   w.group_ = (int)(threadIdx.x / (64u * C::G));
   w.group_stride_ = C::kGroupLds;
-  w.team_base_ = smem + (size_t)C::N * 8;
+  w.team_base_ = smem + C::kTwBytes;
   unsigned char* base = w.team_base_ + (size_t)w.group_ * C::kGroupLds;
   w.tw_ = tw;
   w.scratch_ = reinterpret_cast<elem*>(base);
@@ -106,7 +107,7 @@ __global__ void __launch_bounds__(256) bsk_prepare_kernel(const typename F::elem
   constexpr int N = 1 << LOGN;
   constexpr int G = GroupOf<LOGN>::value;
   elem* twl = reinterpret_cast<elem*>(g_smem);
-  for (int i = threadIdx.x; i < N; i += blockDim.x) twl[i] = tw[i];
+  for (int i = threadIdx.x; i < ntt_twiddle_words(N); i += blockDim.x) twl[i] = tw[i];
   __syncthreads();
   const int group = (int)(threadIdx.x / (64u * G));
   const int groups = (int)(blockDim.x / (64u * G));
@@ -122,7 +123,7 @@ __global__ void __launch_bounds__(256) bsk_prepare_kernel(const typename F::elem
   w.group_stride_ = 0;
   w.team_base_ = nullptr;
   w.tw_ = twl;
-  w.scratch_ = reinterpret_cast<elem*>(g_smem + (size_t)N * 8 + (size_t)group * N * 8);
+  w.scratch_ = reinterpret_cast<elem*>(g_smem + (size_t)ntt_twiddle_words(N) * 8 + (size_t)group * N * 8);
   w.acc_ = nullptr;
   bsk_prepare_wave<F, LOGN, G>(w, polys + poly * N, spectra + poly * N * F::kParts, n_inv);
 }
@@ -362,11 +363,11 @@ __global__ void sample_extract_kernel(u32 log_n, u32 k, const u32* __restrict__ 
   }
 }
 
-__global__ void lwe_gate_input_kernel(const u32* __restrict__ ct0, const u32* __restrict__ ct1,
-                                      size_t words, u32* __restrict__ out) {
+__global__ void lwe_linear_kernel(u32 c0, const u32* ct0, u32 c1, const u32* ct1, size_t words,
+                                  u32* out) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words;
        i += (size_t)gridDim.x * blockDim.x)
-    out[i] = ct1[i] * 2u + ct0[i];
+    out[i] = c0 * ct0[i] + (ct1 ? c1 * ct1[i] : 0u);
 }
 
 inline int grid_for(size_t work, int block) {
@@ -426,7 +427,7 @@ hipError_t launch_bsk_prepare(hipStream_t s, const void* tw_v, const u32* polys,
   constexpr int N = 1 << LOGN;
   constexpr int G = GroupOf<LOGN>::value;
   constexpr int groups = 4 / G;  // polynomials per 256-thread workgroup
-  const size_t lds = (size_t)N * 8 * (1 + groups);
+  const size_t lds = (size_t)ntt_twiddle_words(N) * 8 + (size_t)N * 8 * groups;
   auto tw = static_cast<const typename F::elem*>(tw_v);
   auto spectra = static_cast<typename F::elem*>(spectra_v);
   auto kern = bsk_prepare_kernel<F, LOGN>;
@@ -584,8 +585,9 @@ hipError_t sample_extract(hipStream_t s, u32 log_n, u32 k, const u32* glwe, size
   return hipGetLastError();
 }
 
-hipError_t lwe_gate_input(hipStream_t s, const u32* ct0, const u32* ct1, size_t words, u32* out) {
-  hipLaunchKernelGGL(lwe_gate_input_kernel, dim3(grid_for(words, 256)), dim3(256), 0, s, ct0, ct1,
+hipError_t lwe_linear(hipStream_t s, u32 c0, const u32* ct0, u32 c1, const u32* ct1, size_t words,
+                      u32* out) {
+  hipLaunchKernelGGL(lwe_linear_kernel, dim3(grid_for(words, 256)), dim3(256), 0, s, c0, ct0, c1, ct1,
                      words, out);
   return hipGetLastError();
 }

@@ -52,8 +52,9 @@ hipError_t glwe_mul_monomial(hipStream_t s, u32 log_n, u32 polys_per_ct, const u
                              size_t batch, const i64* monomial_index, u32* out);
 hipError_t sample_extract(hipStream_t s, u32 log_n, u32 k, const u32* glwe, size_t batch,
                           u32 sample_index, u32* lwe_out);
-// out = 2*ct1 + ct0 (boolean.rs:18)
-hipError_t lwe_gate_input(hipStream_t s, const u32* ct0, const u32* ct1, size_t words, u32* out);
+// out = c0*ct0 + c1*ct1 (ct1 may be null when c1 == 0); lwe.rs:9-23, boolean.rs:18
+hipError_t lwe_linear(hipStream_t s, u32 c0, const u32* ct0, u32 c1, const u32* ct1, size_t words,
+                      u32* out);
 
 }  // namespace launch
 }  // namespace tfhe

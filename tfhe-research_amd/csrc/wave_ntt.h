@@ -23,6 +23,8 @@
 //
 // One twiddle table serves both directions: psi_rev[k] = psi^bitrev(k), and
 // psi^-bitrev(h+i) = -psi_rev[2h-1-i], so the inverse butterfly is (V-U) * psi_rev[2h-1-i].
+// The table has kTwiddleWords = N + 2 elements: [N], [N+1] hold psi_rev[1]*psi_rev[2] and
+// psi_rev[1]*psi_rev[3] for the fused first two stages.
 //
 // The arithmetic is a field policy F (field_gl.h: Goldilocks u64, field_fp.h: 42-bit prime in
 // fp64); elements are 8 bytes in both, so layouts, swizzles and LDS budgets are identical.
@@ -34,6 +36,9 @@
 #include "field_gl.h"
 
 namespace tfhe {
+
+// elements of the twiddle table of a ring of degree n (see above)
+constexpr int ntt_twiddle_words(int n) { return n + 2; }
 
 template <int LOGN, int G = 1>
 struct NttShape {
@@ -102,8 +107,21 @@ TFHE_HD void ntt_pass_forward(const Ctx& c, typename F::elem (&x)[NttShape<LOGN,
   constexpr int e = NttShape<LOGN, G>::kEBits;
   const elem* tw = c.twiddles();
   const int hi = c.tid() >> LO;
+  // The two top stages of the whole transform on small inputs (gadget digits): in a field with
+  // kFuseFirstTwo they collapse into one exact radix-4 step without any modular reduction
+  // (F::radix4_small).  Twiddles: psi_rev[1], psi_rev[2], psi_rev[3] and their two products
+  // psi_rev[1]*psi_rev[2], psi_rev[1]*psi_rev[3], which fill_twiddles stores at [N] and [N+1].
+  constexpr bool FUSE = SMALL_FIRST && F::kFuseFirstTwo && BHI == LOGN - 1 && BHI - BLO >= 1;
+  if constexpr (FUSE) {
+    constexpr int N = NttShape<LOGN, G>::kN;
+    constexpr int s1 = 1 << (BHI - LO), s2 = s1 >> 1;
+    const elem w1 = tw[1], w2a = tw[2], w2b = tw[3], w12a = tw[N], w12b = tw[N + 1];
 #pragma unroll
-  for (int b = BHI; b >= BLO; --b) {
+    for (int r = 0; r < s2; ++r)
+      F::radix4_small(x[r], x[r + s2], x[r + s1], x[r + s1 + s2], w1, w2a, w2b, w12a, w12b);
+  }
+#pragma unroll
+  for (int b = FUSE ? BHI - 2 : BHI; b >= BLO; --b) {
     const int rb = b - LO;
     const int m = NttShape<LOGN, G>::kN >> (b + 1);
     const int base = m + (hi << (LO + e - b - 1));
