@@ -256,7 +256,7 @@ TFHE_HD void blind_rotate_team(const Ctx& c, const PbsParams& P, const u32* lwe 
     auto src = [&](int j) -> u32 { return monomial_coeff<LOGN>(acc, j, a_tilde) - acc[j]; };
     // all rotated reads of acc happen before the first inverse transform: in-place update is safe
     auto out = [&](int j, u32 value) { acc[j] += value; };
-    external_product_team<F, LOGN, K, G>(c, P, bsk + (size_t)i * ggsw_words, src, out);
+        external_product_team<F, LOGN, K, G>(c, P, bsk + (size_t)i * ggsw_words, src, out);
     c.poly_sync();
   }
 }
