@@ -91,6 +91,69 @@ def cpu_baseline(workload: str, budget_s: float):
     }
 
 
+def bench_external_product(args, pkg, params, batch, dev, rand_words, world, rank, local_rank, backend):
+    """Standalone external product (ggsw.rs:132-161): out[b] = GGSW (x) GLWE[b] with the GGSW already in
+    the NTT domain.  Shared GGSW = the blind-rotation shape; --ggsw-per-sample streams one prepared
+    GGSW per sample from HBM.  Algorithmic bytes per product: 4*N*(k+1)*((k+1)*l + 2)."""
+    import torch
+    import torch.distributed as dist
+    ctx = pkg.Context(params, device=local_rank, backend=backend)
+    ctx.use_torch_stream()
+    ctx.set_timing(True)
+    count = batch if args.ggsw_per_sample else 1
+    ggsw = rand_words(count, params.R, params.k + 1, params.N)
+    prepared = ctx.prepare_ggsw_device(ggsw)
+    glwe = rand_words(batch, params.k + 1, params.N)
+    out = torch.empty_like(glwe)
+    use_dist = dist.is_initialized()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    steps = max(args.steps, 20)
+    for _ in range(max(args.warmup, 3)):
+        ctx.external_product_prepared(prepared, glwe, out=out)
+    barrier()
+    kms = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.external_product_prepared(prepared, glwe, out=out)
+        kms.append(ctx.last_kernel_ms()[0])
+    barrier()
+    dt = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    kernel_ms = float(np.mean(kms))
+    algo = batch * params.external_product_bytes()
+    physical = (count * prepared.shape[1] * 8) + 2 * batch * (params.k + 1) * params.N * 4
+    achieved = algo / (kernel_ms * 1e-3) / 1e9
+    result = {
+        "metric": "external_products_per_sec", "value": batch * world * steps / dt, "unit": "products/s",
+        "n_gpus": world, "steps": steps, "warmup": max(args.warmup, 3), "ms_per_step": dt / steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64" if ctx.backend.startswith("fp64") else "u64", "data": "synthetic",
+        "config": {"workload": f"external_product {args.workload}: batch {batch}/GPU, N={params.N}, k={params.k}, "
+                               f"l={params.pbs_decomposer.levels}, log2B={params.pbs_decomposer.log_base}, "
+                               + ("one prepared GGSW per sample" if args.ggsw_per_sample else "one GGSW shared by the batch")},
+        "roofline": {"kernel": f"external_product_kernel<{ctx.backend},{params.glwe_poly_degree},{params.k}>",
+                     "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_hbm": achieved / HBM_MEASURED_GBS,
+                     "traffic": None, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo,
+                     "physical_operand_bytes_per_launch": physical,
+                     "physical_GBps": physical / (kernel_ms * 1e-3) / 1e9},
+    }
+    ctx.close()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if use_dist:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,6 +164,10 @@ def main():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="auto", choices=["auto", "goldilocks", "fp64"])
+    ap.add_argument("--kernel", default="bootstrap", choices=["bootstrap", "external_product"],
+                    help="external_product: time the standalone GGSW x GLWE kernel (ggsw.rs:132-161) instead of the PBS")
+    ap.add_argument("--ggsw-per-sample", action="store_true",
+                    help="external_product only: one prepared GGSW per sample (streams from HBM) instead of one shared by the batch")
     ap.add_argument("--gate", default="", choices=["", "nand", "and", "or", "xor"],
                     help="step = one homomorphic gate over the batch (boolean.rs: bootstrap(2*ct1 + ct0)) instead of a plain PBS")
     args = ap.parse_args()
@@ -144,6 +211,8 @@ def main():
     out = torch.empty_like(lwe)
 
     backend = {"auto": pkg.BACKEND_AUTO, "goldilocks": pkg.BACKEND_GOLDILOCKS, "fp64": pkg.BACKEND_FP64}[args.backend]
+    if args.kernel == "external_product":
+        return bench_external_product(args, pkg, params, batch, dev, rand_words, world, rank, local_rank, backend)
     ctx = pkg.Context(params, device=local_rank, backend=backend)
     backend_name = ctx.backend
     ctx.use_torch_stream()
