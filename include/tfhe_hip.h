@@ -91,8 +91,11 @@ int tfhe_context_create_with_backend(const tfhe_params *params, int device, int 
 /* "fp64-p42" or "goldilocks" */
 const char *tfhe_context_backend(const tfhe_context *ctx);
 void tfhe_context_destroy(tfhe_context *ctx);
-/* Use an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream. */
+/* Run on an existing hipStream_t, e.g. torch.cuda.current_stream().cuda_stream.  A NULL handle is
+ * HIP's default stream (that is what torch hands out unless the caller switched streams).  A new
+ * context starts on a private non-blocking stream; tfhe_context_use_own_stream goes back to one. */
 int tfhe_context_set_stream(tfhe_context *ctx, void *hip_stream);
+int tfhe_context_use_own_stream(tfhe_context *ctx);
 int tfhe_context_synchronize(tfhe_context *ctx);
 /* Pre-sizes the per-batch workspace so that later _device calls up to `max_batch` never allocate. */
 int tfhe_context_reserve(tfhe_context *ctx, size_t max_batch);

@@ -348,3 +348,43 @@ def test_batch_edge_cases(oracle, contexts):
     with pytest.raises(m.TfheError) as e:
         ctx.bootstrap(np.zeros((0, p.n + 1), dtype=np.uint32), tv)
     assert e.value.status == 5
+
+
+def test_encrypted_adder_gate_graph(oracle):
+    """a graph of AND/OR/XOR gates evaluated with all ciphertexts resident on the device
+    (tfhe_gate_batch_device, gates of one level batched): 32 independent 4-bit ripple-carry adders
+    under real keys with the reference's cfg(test)-sized LWE key.  Every decrypted sum must equal
+    a + b, and sampled wires must be bit-exact with the oracle gate by gate."""
+    import importlib
+    import torch
+    p = oracle.Params(2, 9, 16, oracle.Decomposer(4, 6))  # reference defaults with a short LWE key
+    rng = oracle.Rng(777)
+    lwe_sk, glwe_sk, bsk, ksk = oracle.keygen(p, rng)
+    m = pkg()
+    gates = importlib.import_module("tfhe_research_amd.gates")
+    circuit, out_wires = gates.ripple_carry_adder(4)
+    inst = 32
+    nprng = np.random.default_rng(3)
+    a, b = nprng.integers(0, 16, size=inst), nprng.integers(0, 16, size=inst)
+    bits = np.array([[(a[i] >> j) & 1 for j in range(4)] + [(b[i] >> j) & 1 for j in range(4)] for i in range(inst)])
+    cts = np.stack([np.stack([oracle.encrypt_lwe(p, lwe_sk, int(bit), rng) for bit in row]) for row in bits])
+    dev = torch.device("cuda", 0)
+    with m.Context(to_pkg_params(p)) as ctx:
+        ctx.load_bootstrapping_key(bsk, ksk)
+        ctx.use_torch_stream()
+        wires = gates.evaluate(ctx, circuit, torch.from_numpy(cts.view(np.int32)).to(dev))
+        torch.cuda.synchronize()
+        wires = wires.cpu().numpy().view(np.uint32)
+        ctx.set_stream(None)
+    for i in range(inst):
+        clear = circuit.evaluate_clear(bits[i].tolist())
+        got = [oracle.decrypt_lwe_message(p, lwe_sk, wires[i, w]) for w in range(circuit.n_wires)]
+        assert got == clear, i
+        total = sum(got[w] << j for j, w in enumerate(out_wires))
+        assert total == a[i] + b[i]
+    # gate-by-gate bit-exactness on a few wires of instance 0 (inputs of each gate taken from the GPU run)
+    fns = {"and": lambda l, r: l & r, "or": lambda l, r: l | r, "xor": lambda l, r: l ^ r}
+    for g in (0, 5, len(circuit.gates) - 1):
+        kind, lhs, rhs = circuit.gates[g]
+        want = oracle.boolean_gate(p, fns[kind], wires[0, rhs], wires[0, lhs], bsk, ksk)
+        assert np.array_equal(wires[0, circuit.n_inputs + g], want), g

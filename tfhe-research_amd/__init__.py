@@ -253,7 +253,11 @@ class Context:
         return w.value
 
     def set_stream(self, hip_stream: int | None):
-        self._check(lib().tfhe_context_set_stream(self._h, C.c_void_p(hip_stream or 0)))
+        """hip_stream: a hipStream_t handle (0 = HIP's default stream); None = back to a private stream."""
+        if hip_stream is None:
+            self._check(lib().tfhe_context_use_own_stream(self._h))
+        else:
+            self._check(lib().tfhe_context_set_stream(self._h, C.c_void_p(hip_stream)))
 
     def use_torch_stream(self):
         import torch

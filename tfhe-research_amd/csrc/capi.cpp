@@ -345,7 +345,7 @@ int tfhe_prepared_ggsw_words(const tfhe_context* ctx, size_t* words) {
 void tfhe_context_destroy(tfhe_context* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
-  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  (void)hipStreamSynchronize(ctx->stream);
   void* ptrs[] = {ctx->d_tw,     ctx->d_bsk,    ctx->d_ksk,    ctx->d_lwe_in, ctx->d_lwe_in2,
                   ctx->d_lwe_big, ctx->d_lwe_out, ctx->d_glwe_a, ctx->d_glwe_b, ctx->d_glwe_c,
                   ctx->d_tv,     ctx->d_tv_gate, ctx->d_misc,   ctx->d_ggsw_tmp, ctx->d_ggsw_raw};
@@ -360,15 +360,22 @@ void tfhe_context_destroy(tfhe_context* ctx) {
 int tfhe_context_set_stream(tfhe_context* ctx, void* hip_stream) {
   int st = check_ctx(ctx);
   if (st) return st;
-  if (ctx->stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->stream || !ctx->own_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   if (ctx->own_stream && ctx->stream) HIP_TRY(ctx, hipStreamDestroy(ctx->stream));
-  if (hip_stream) {
-    ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
-    ctx->own_stream = false;
-  } else {
-    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    ctx->own_stream = true;
-  }
+  // a null handle is HIP's default stream, which is what torch.cuda.current_stream().cuda_stream
+  // is unless the caller switched streams
+  ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+  ctx->own_stream = false;
+  return TFHE_OK;
+}
+
+int tfhe_context_use_own_stream(tfhe_context* ctx) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  if (ctx->own_stream) return TFHE_OK;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  ctx->own_stream = true;
   return TFHE_OK;
 }
 
