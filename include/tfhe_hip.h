@@ -77,18 +77,21 @@ int tfhe_params_validate(const tfhe_params *params);
  *   FP64       42-bit prime, fp64 arithmetic, key split into 16-bit halves; needs
  *              (k+1)*l * N * B * 2^15 < 2^40.9 and log_base <= 9
  *   GOLDILOCKS p = 2^64 - 2^32 + 1, u64 arithmetic; needs (k+1)*l * N * B * 2^32 < 2^62
- *   AUTO       FP64 when its bound holds, else GOLDILOCKS (env TFHE_HIP_BACKEND=fp64|goldilocks
- *              overrides AUTO). */
+ *   GOLDILOCKS_SPLIT  the same field with the key split into 16-bit halves; needs
+ *              (k+1)*l * N * B * 2^15 < 2^62, which every base the reference can express satisfies
+ *   AUTO       the first of FP64, GOLDILOCKS, GOLDILOCKS_SPLIT whose bound holds (env
+ *              TFHE_HIP_BACKEND=fp64|goldilocks|goldilocks-split overrides AUTO). */
 #define TFHE_BACKEND_AUTO 0
 #define TFHE_BACKEND_GOLDILOCKS 1
 #define TFHE_BACKEND_FP64 2
+#define TFHE_BACKEND_GOLDILOCKS_SPLIT 3
 
 /* Creates a context bound to HIP device `device`.  Fails with TFHE_ERR_NO_DEVICE when no GPU is
  * present: there is deliberately no CPU path behind this ABI. */
 int tfhe_context_create(const tfhe_params *params, int device, tfhe_context **out);
 int tfhe_context_create_with_backend(const tfhe_params *params, int device, int backend,
                                      tfhe_context **out);
-/* "fp64-p42" or "goldilocks" */
+/* "fp64-p42", "goldilocks" or "goldilocks-split" */
 const char *tfhe_context_backend(const tfhe_context *ctx);
 void tfhe_context_destroy(tfhe_context *ctx);
 /* Run on an existing hipStream_t, e.g. torch.cuda.current_stream().cuda_stream.  A NULL handle is

@@ -36,8 +36,8 @@ def emu():
     return lib
 
 
-GL, FP = 1, 2
-FIELDS = [GL, FP]
+GL, FP, GLS = 1, 2, 3  # Goldilocks, fp64 prime, Goldilocks with the key split in 16-bit halves
+FIELDS = [GL, FP, GLS]
 
 
 def pd(a):
@@ -248,3 +248,20 @@ def test_blind_rotate_and_extract_vs_oracle(emu, oracle, field, k, logn, n, pbs,
         _, tr = oracle.bootstrap(params, lwe[b], bsk, ksk, tv, trace=True)
         assert np.array_equal(glwe[b], tr["acc_final"]), f"sample {b}"
         assert np.array_equal(ext[b], tr["extracted_lwe"]), f"sample {b}"
+
+
+def test_wide_base_needs_split_goldilocks(emu, oracle):
+    """log_base = 23, l = 1 at N = 2048 (the shape of modern one-level parameter sets): the plain
+    convolution bound 2 * 2048 * 2^23 * 2^32 = 2^67 exceeds Goldilocks, the split field lifts it."""
+    params = oracle.Params(1, 11, 1, oracle.Decomposer(23, 1))
+    rng = np.random.default_rng(23)
+    ggsw = rng.integers(0, 1 << 32, size=(params.R, 2, params.N), dtype=np.uint64).astype(np.uint32)
+    glwe = rng.integers(0, 1 << 32, size=(2, params.N), dtype=np.uint64).astype(np.uint32)
+    # adversarial: every digit at the extreme, key halves at their bounds, signs aligned
+    glwe[0, :] = 0x7FFFFE00
+    ggsw[:, :, 0] = 0x7FFF7FFF
+    ggsw[:, :, 1:] = np.uint32(0x80008001)  # = -0x7FFF7FFF mod 2^32
+    spec = prepared(emu, GLS, params, ggsw, 2)
+    out = np.zeros_like(glwe)
+    assert emu.emu_external_product(GLS, 2, 1, 11, 23, 1, p64(spec), p32(glwe), p32(out)) == 0
+    assert np.array_equal(out, oracle.external_product(params, ggsw, glwe))

@@ -22,12 +22,13 @@ def make(oracle, k, logn, n, pbs, ks, log_p):
     return oracle.Params(k, logn, n, oracle.Decomposer(*pbs), oracle.Decomposer(*ks), log_p=log_p)
 
 
-BACKENDS = ["fp64", "goldilocks"]
+BACKENDS = ["fp64", "goldilocks", "goldilocks-split"]
 
 
 def backend_id(name):
     m = pkg()
-    return {"fp64": m.BACKEND_FP64, "goldilocks": m.BACKEND_GOLDILOCKS, "auto": m.BACKEND_AUTO}[name]
+    return {"fp64": m.BACKEND_FP64, "goldilocks": m.BACKEND_GOLDILOCKS, "auto": m.BACKEND_AUTO,
+            "goldilocks-split": m.BACKEND_GOLDILOCKS_SPLIT}[name]
 
 
 def fp64_exact(p):
@@ -67,7 +68,7 @@ def contexts(oracle):
 @pytest.mark.parametrize("name", [s[0] for s in SHAPES])
 def test_bootstrap_matches_oracle(oracle, contexts, name, backend):
     p, ctx, lwe, bsk, ksk, tv = contexts(name, backend)
-    assert ctx.backend.startswith(backend[:4])
+    assert ctx.backend == {"fp64": "fp64-p42"}.get(backend, backend)
     got = ctx.bootstrap(lwe, tv)
     glwe = ctx.blind_rotate(lwe, tv)
     for b in range(lwe.shape[0]):
@@ -218,6 +219,7 @@ def test_full_size_cfg2_sample_parity(oracle):
             # determinism: same inputs, same bits
             assert np.array_equal(outs[backend], ctx.bootstrap(lwe, tv))
     assert np.array_equal(outs["fp64"], outs["goldilocks"])
+    assert np.array_equal(outs["fp64"], outs["goldilocks-split"])
     for b in (0, 31, 63):
         assert np.array_equal(outs["fp64"][b], oracle.bootstrap(p, lwe[b], bsk, ksk, tv)), b
 
@@ -233,6 +235,19 @@ def test_backend_selection(oracle):
         assert ctx.backend == "goldilocks"
     with pytest.raises(m.TfheError) as e:
         m.Context(wide, backend=m.BACKEND_FP64)
+    assert e.value.status == 7
+    # one-level decomposition with a 23-bit base at N = 2048: 2 * 2048 * 2^23 * 2^32 = 2^67 is beyond
+    # plain Goldilocks, so AUTO falls through to the split-key field -- and it is still bit-exact
+    p = oracle.Params(1, 11, 3, oracle.Decomposer(23, 1))
+    with m.Context(to_pkg_params(p)) as ctx:
+        assert ctx.backend == "goldilocks-split"
+        lwe, bsk, ksk, tv = oracle.synthetic_inputs(p, 3, cfg_index=23)
+        ctx.load_bootstrapping_key(bsk, ksk)
+        out = ctx.bootstrap(lwe, tv)
+    for b in range(3):
+        assert np.array_equal(out[b], oracle.bootstrap(p, lwe[b], bsk, ksk, tv)), b
+    with pytest.raises(m.TfheError) as e:
+        m.Context(to_pkg_params(p), backend=m.BACKEND_GOLDILOCKS)
     assert e.value.status == 7
 
 

@@ -26,7 +26,7 @@ STATUS_NAMES = {
     4: "TFHE_ERR_HIP", 5: "TFHE_ERR_INVALID_ARGUMENT", 6: "TFHE_ERR_NO_DEVICE", 7: "TFHE_ERR_EXACTNESS",
 }
 DECOMPOSER_PBS, DECOMPOSER_KS = 0, 1
-BACKEND_AUTO, BACKEND_GOLDILOCKS, BACKEND_FP64 = 0, 1, 2
+BACKEND_AUTO, BACKEND_GOLDILOCKS, BACKEND_FP64, BACKEND_GOLDILOCKS_SPLIT = 0, 1, 2, 3
 
 # truth[(lhs << 1) | rhs]
 GATE_AND = (0, 0, 0, 1)

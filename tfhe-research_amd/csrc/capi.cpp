@@ -268,17 +268,22 @@ int tfhe_context_create_with_backend(const tfhe_params* params, int device, int 
   const bool fp_ok = convolution_bits(params, FpField::key_bits()) < FpField::exact_bits() &&
                      params->pbs_decomposer.log_base <= (uint32_t)FpField::kSmallBits;
   const bool gl_ok = convolution_bits(params, GlField::key_bits()) < GlField::exact_bits();
+  const bool gls_ok = convolution_bits(params, GlSplitField::key_bits()) < GlSplitField::exact_bits();
   int field = 0;
   if (backend == TFHE_BACKEND_AUTO) {
     const char* env = std::getenv("TFHE_HIP_BACKEND");
     if (env && std::strcmp(env, "goldilocks") == 0) backend = TFHE_BACKEND_GOLDILOCKS;
     else if (env && std::strcmp(env, "fp64") == 0) backend = TFHE_BACKEND_FP64;
+    else if (env && std::strcmp(env, "goldilocks-split") == 0) backend = TFHE_BACKEND_GOLDILOCKS_SPLIT;
   }
-  if (backend == TFHE_BACKEND_AUTO) field = fp_ok ? launch::kFieldFp64 : launch::kFieldGoldilocks;
+  if (backend == TFHE_BACKEND_AUTO)
+    field = fp_ok ? launch::kFieldFp64 : gl_ok ? launch::kFieldGoldilocks : launch::kFieldGoldilocksSplit;
   else if (backend == TFHE_BACKEND_GOLDILOCKS) field = launch::kFieldGoldilocks;
   else if (backend == TFHE_BACKEND_FP64) field = launch::kFieldFp64;
+  else if (backend == TFHE_BACKEND_GOLDILOCKS_SPLIT) field = launch::kFieldGoldilocksSplit;
   else return TFHE_ERR_INVALID_ARGUMENT;
-  if ((field == launch::kFieldFp64 && !fp_ok) || (field == launch::kFieldGoldilocks && !gl_ok))
+  if ((field == launch::kFieldFp64 && !fp_ok) || (field == launch::kFieldGoldilocks && !gl_ok) ||
+      (field == launch::kFieldGoldilocksSplit && !gls_ok))
     return TFHE_ERR_EXACTNESS;
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count)
@@ -319,7 +324,7 @@ int tfhe_context_create_with_backend(const tfhe_params* params, int device, int 
   ctx->own_stream = true;
   for (auto& ev : ctx->ev)
     if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e, "hipEventCreate");
-  e = field == launch::kFieldFp64 ? upload_twiddles<FpField>(ctx) : upload_twiddles<GlField>(ctx);
+  e = field == launch::kFieldFp64 ? upload_twiddles<FpField>(ctx) : upload_twiddles<GlField>(ctx);  // both Goldilocks fields share the table
   if (e != hipSuccess) return bail(e, "twiddle upload");
   if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->d_tv_gate), ctx->N * sizeof(u32))) != hipSuccess)
     return bail(e, "hipMalloc gate tv");
@@ -333,7 +338,8 @@ int tfhe_context_create(const tfhe_params* params, int device, tfhe_context** ou
 
 const char* tfhe_context_backend(const tfhe_context* ctx) {
   if (!ctx) return "";
-  return ctx->field == launch::kFieldFp64 ? "fp64-p42" : "goldilocks";
+  return ctx->field == launch::kFieldFp64 ? "fp64-p42"
+         : ctx->field == launch::kFieldGoldilocks ? "goldilocks" : "goldilocks-split";
 }
 
 int tfhe_prepared_ggsw_words(const tfhe_context* ctx, size_t* words) {

@@ -1,14 +1,18 @@
 // field_gl.h -- field policy: Goldilocks prime p = 2^64 - 2^32 + 1, elements u64 (goldilocks.h).
-// One spectrum per key polynomial.  Exact for every parameter set with R*N*B*2^32 < 2^62.
+//   GlField      (PARTS = 1): one spectrum per key polynomial; exact when R*N*B*2^32 < 2^62.
+//   GlSplitField (PARTS = 2): the key word is split into signed 16-bit halves like in the fp64 field;
+//                exact when R*N*B*2^15 < 2^62, i.e. for every decomposition base the reference can
+//                express (log_base <= 31) at N <= 2048.  The last resort of the backend selection.
 #pragma once
 #include "goldilocks.h"
 
 namespace tfhe {
 
-struct GlField {
+template <int PARTS>
+struct GlFieldT {
   typedef u64 elem;
-  static constexpr int kParts = 1;  // spectra per bootstrapping-key polynomial
-  static constexpr int kId = 1;
+  static constexpr int kParts = PARTS;  // spectra per bootstrapping-key polynomial
+  static constexpr int kId = PARTS == 1 ? 1 : 3;
 
   TFHE_HD static elem zero() { return 0; }
   TFHE_HD static elem add(elem a, elem b) { return gl::add(a, b); }
@@ -21,11 +25,20 @@ struct GlField {
   // gadget digit (wrapped u32 holding a small signed integer) -> field element
   TFHE_HD static elem from_digit(u32 d) { return gl::from_i32(d); }
   // key word -> field element of spectrum `part`
-  TFHE_HD static elem from_key_word(u32 w, int /*part*/) { return (elem)w; }
+  TFHE_HD static elem from_key_word(u32 w, int part) {
+    if (PARTS == 1) return (elem)w;
+    // signed 16-bit halves of the word taken as a signed 32-bit integer: w = lo + 2^16 hi (mod 2^32)
+    const i32 lo = (i32)(int16_t)(w & 0xFFFFu);
+    return gl::from_i32((u32)(part == 0 ? lo : (((i32)w - lo) >> 16)));
+  }
   // called on every accumulator before the inverse transform
   TFHE_HD static elem before_inverse(elem a) { return a; }
   // inverse-transform outputs of all parts -> value mod 2^32
-  TFHE_HD static u32 finish(const elem (&parts)[kParts]) { return gl::lift_mod_2_32(parts[0]); }
+  TFHE_HD static u32 finish(const elem (&parts)[kParts]) {
+    u32 v = gl::lift_mod_2_32(parts[0]);
+    if (PARTS == 2) v += gl::lift_mod_2_32(parts[PARTS - 1]) << 16;
+    return v;
+  }
 
   // ---- host-side constants ----
   // out: n + 2 elements (wave_ntt.h::ntt_twiddle_words)
@@ -46,7 +59,10 @@ struct GlField {
   // log2 of the largest |integer convolution value| this field lifts exactly
   static inline double exact_bits() { return 62.0; }
   // log2 of the magnitude of one key operand as seen by the convolution
-  static inline double key_bits() { return 32.0; }
+  static inline double key_bits() { return PARTS == 1 ? 32.0 : 15.0; }
 };
+
+typedef GlFieldT<1> GlField;
+typedef GlFieldT<2> GlSplitField;
 
 }  // namespace tfhe

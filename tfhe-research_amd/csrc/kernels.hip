@@ -447,7 +447,7 @@ bool shape_supported(u32 log_n, u32 k) { return log_n >= 9 && log_n <= 11 && (k 
 
 int waves_per_block(u32 log_n, u32 k) { return ((int)k + 1) * (log_n >= 11 ? 2 : 1); }
 
-int field_parts(int field) { return field == kFieldFp64 ? FpField::kParts : GlField::kParts; }
+int field_parts(int field) { return field == kFieldGoldilocks ? 1 : 2; }
 
 // (field, log_n, k) -> template instantiation.  TFHE_DEV_CFG2_ONLY builds just the BASELINE cfg2
 // shape (N = 1024, k = 1) for fast iteration on the kernels.
@@ -502,6 +502,9 @@ int field_parts(int field) { return field == kFieldFp64 ? FpField::kParts : GlFi
       BODY                                                                    \
     } else if ((field) == kFieldFp64) {                                       \
       typedef FpField FF;                                                     \
+      BODY                                                                    \
+    } else if ((field) == kFieldGoldilocksSplit) {                            \
+      typedef GlSplitField FF;                                                \
       BODY                                                                    \
     }                                                                         \
     return hipErrorInvalidValue;                                              \

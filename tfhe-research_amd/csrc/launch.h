@@ -10,6 +10,7 @@ namespace launch {
 // NTT backends (field policies): values of the `field` argument below
 constexpr int kFieldGoldilocks = GlField::kId;  // 1
 constexpr int kFieldFp64 = FpField::kId;        // 2
+constexpr int kFieldGoldilocksSplit = GlSplitField::kId;  // 3
 
 // true if a kernel set is instantiated for (log_n, k)
 bool shape_supported(u32 log_n, u32 k);
