@@ -181,6 +181,9 @@ def main():
                     help="external_product: time the standalone GGSW x GLWE kernel (ggsw.rs:132-161) instead of the PBS")
     ap.add_argument("--ggsw-per-sample", action="store_true",
                     help="external_product only: one prepared GGSW per sample (streams from HBM) instead of one shared by the batch")
+    ap.add_argument("--scatter-gather", action="store_true",
+                    help="include the RCCL scatter of the input batch from rank 0 and the gather of the results "
+                         "in every step (tfhe_research_amd.sharding); default: shards are resident per rank")
     ap.add_argument("--gate", default="", choices=["", "nand", "and", "or", "xor"],
                     help="step = one homomorphic gate over the batch (boolean.rs: bootstrap(2*ct1 + ct0)) instead of a plain PBS")
     args = ap.parse_args()
@@ -247,6 +250,17 @@ def main():
 
         def step():
             ctx.gate(truth, lwe, lwe2, out=out)
+    elif args.scatter_gather:
+        if not use_dist:
+            raise SystemExit("--scatter-gather needs torch.distributed.run (RANK/WORLD_SIZE in the environment)")
+        import importlib
+        sharding = importlib.import_module("tfhe_research_amd.sharding")
+        full = rand_words(batch * world, n + 1) if rank == 0 else None
+
+        def step():
+            # rank 0 owns the whole batch: scatter rows over RCCL, bootstrap the local shard, gather
+            sharding.bootstrap_sharded(lambda shard, tvv: ctx.bootstrap(shard, tvv), full, tv, root=0,
+                                       batch=batch * world, width=n + 1, like=lwe)
     else:
         def step():
             ctx.bootstrap(lwe, tv, out=out)
@@ -295,7 +309,8 @@ def main():
             "workload": f"{args.workload}: batch {batch}/GPU, N={1 << logn}, k={k}, n={n}, l={pbs[1]}, log2B={pbs[0]}, "
                         f"KS l={ks[1]} log2B={ks[0]}, log_p={log_p}, " + (f"{args.gate.upper()} gate stream" if args.gate else "identity LUT"),
             "global_batch": batch * world,
-            "parallelism": f"dp{world} (independent LWE shards, keys replicated)",
+            "parallelism": f"dp{world} (independent LWE shards, keys replicated"
+                           + (", batch scattered from / gathered to rank 0 over RCCL every step)" if args.scatter_gather else ")"),
         },
         "roofline": {
             "kernel": kernel_name,
