@@ -302,8 +302,9 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": ("f64 (exact NTT mod a 42-bit prime; data is wrapping u32)" if backend_name.startswith("fp64")
-                  else "u64 (exact Goldilocks NTT; data is wrapping u32)"),
+        "dtype": "f64" if backend_name.startswith("fp64") else "u64",
+        "dtype_note": ("exact NTT over the 42-bit prime 2^42-24575 in fp64" if backend_name.startswith("fp64")
+                       else "exact NTT over the Goldilocks prime in u64") + "; ciphertext words are wrapping u32",
         "data": "synthetic",
         "config": {
             "workload": f"{args.workload}: batch {batch}/GPU, N={1 << logn}, k={k}, n={n}, l={pbs[1]}, log2B={pbs[0]}, "

@@ -16,8 +16,6 @@ constexpr int kFieldGoldilocksSplit = GlSplitField::kId;  // 3
 bool shape_supported(u32 log_n, u32 k);
 // spectra per key polynomial for a field (1 or 2)
 int field_parts(int field);
-// waves (= samples) per workgroup used by the per-wave kernels for this shape
-int waves_per_block(u32 log_n, u32 k);
 
 // twiddle table psi_rev[N] (8-byte field elements) must already be on the device;
 // spectra: poly_count x field_parts x N elements

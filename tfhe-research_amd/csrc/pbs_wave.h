@@ -1,11 +1,11 @@
 // pbs_wave.h -- per-wavefront bodies of the bootstrapping hot path (host/device source).
 //
-// A team of K+1 wavefronts (one workgroup) owns one LWE sample for the whole blind rotation: wave c
-// keeps polynomial c of the GLWE accumulator in its private LDS for all n CMUX iterations, the
-// waves exchange only digit spectra through LDS, and the only global traffic inside the loop is the
-// (batch-shared, L2/Infinity-Cache resident) NTT-domain bootstrapping key.  The same bodies are compiled by g++ for the SIMT emulator that
-// the CPU tests use (tests/emu), so what is parity-tested on the CPU is the code that runs on the
-// GPU.
+// A team of K+1 wave groups (one workgroup) owns one LWE sample for the whole blind rotation: group c
+// keeps polynomial c of the GLWE accumulator in LDS for all n CMUX iterations, the groups exchange
+// only digit spectra through LDS, and the only global traffic inside the loop is the batch-shared,
+// L2/Infinity-Cache resident NTT-domain bootstrapping key.  The same bodies are compiled by g++ for
+// the SIMT emulator that the CPU tests use (tests/emu), so what is parity-tested on the CPU is the
+// code that runs on the GPU.
 //
 // Reference behaviour restated here (file:line in /root/reference/src):
 //   switch_modulus            utils.rs:13-33
@@ -167,7 +167,7 @@ TFHE_HD void external_product_team(const Ctx& c, const PbsParams& P, const typen
       // digits are tiny (|d| <= B <= 2^F::kSmallBits, enforced when the context picks the field):
       // the first butterfly stage uses F::mul_small
       ntt_forward<F, LOGN, G, true>(c, work);
-      // publish: element r of lane at [r*64 + lane] (conflict-free 8-byte accesses)
+      // publish: element r of thread tid at [r*T + tid] (conflict-free 8-byte accesses)
       elem* mine = c.scratch();
 #pragma unroll
       for (int r = 0; r < E; ++r) mine[r * T + lane] = work[r];
@@ -256,8 +256,8 @@ TFHE_HD void blind_rotate_team(const Ctx& c, const PbsParams& P, const u32* lwe 
     auto src = [&](int j) -> u32 { return monomial_coeff<LOGN>(acc, j, a_tilde) - acc[j]; };
     // all rotated reads of acc happen before the first inverse transform: in-place update is safe
     auto out = [&](int j, u32 value) { acc[j] += value; };
-        external_product_team<F, LOGN, K, G>(c, P, bsk + (size_t)i * ggsw_words, src, out);
-    c.poly_sync();
+    external_product_team<F, LOGN, K, G>(c, P, bsk + (size_t)i * ggsw_words, src, out);
+    c.poly_sync();  // G > 1: the other wave of my group reads what I just wrote
   }
 }
 
