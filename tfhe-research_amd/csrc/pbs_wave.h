@@ -135,9 +135,13 @@ TFHE_HD void external_product_team(const Ctx& c, const PbsParams& P, const typen
   // polynomial 0..K, q = part.  A tile is consumed in chunks of CH registers; chunks are staged
   // through two register buffers: the loads of chunk i+1 are issued before the arithmetic of chunk
   // i, and chunk 0 of a level is loaded before that level's forward transform, so no key load sits
-  // on the critical path.  CH = 16 keeps the staging at 3 x 32 VGPRs whatever E is.
+  // on the critical path.  CH = 8 keeps the staging at 3 x 16 VGPRs whatever E is (16 measured the
+  // same speed with more spill: profiles/r01_chunk_ab.txt).
+#ifndef TFHE_CHUNK
+#define TFHE_CHUNK 8
+#endif
   constexpr int TILES = (K + 1) * PARTS;
-  constexpr int CH = E < 16 ? E : 16;
+  constexpr int CH = E < TFHE_CHUNK ? E : TFHE_CHUNK;
   constexpr int CHUNKS = TILES * (E / CH);
   auto tile_ptr = [&](u32 level, int idx) -> const elem* {
     const int s = idx / PARTS, q = idx % PARTS;
