@@ -11,7 +11,9 @@
 #include <cstddef>
 #include <cstdint>
 #include <functional>
+#include <cmath>
 #include <memory>
+#include <random>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -43,6 +45,8 @@ struct TfheParams {
   uint32_t log_q = 32;
   DecomposerParams ks_decomposer{4, 5, 32};
   DecomposerParams pbs_decomposer{4, 6, 32};
+  double lwe_std_dev = 0.000013071021089943935;    // lib.rs:96,120
+  double glwe_std_dev = 0.00000004990272175010415;  // lib.rs:97,121
 
   static TfheParams default_params() { return TfheParams{}; }  // lib.rs:101-123
   static TfheParams default_test_params() {                    // lib.rs:77-99
@@ -264,6 +268,178 @@ inline LweCiphertext nand(Engine& e, const LweCiphertext& ct0, const LweCipherte
 inline LweCiphertext xor_(Engine& e, const LweCiphertext& ct0, const LweCiphertext& ct1) {
   const uint32_t t[4] = {0, 1, 1, 0};
   return gate(e, t, ct0, ct1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Encryption side.  The reference threads `rng: &mut R` through keygen and
+// encryption; here `Rng` is any C++ UniformRandomBitGenerator.  The draws happen on the host, in
+// the reference's order (masks with sample_uniform_array, errors with sample_gaussian_array), and
+// land in the output buffer; the GPU then adds the <mask, key> terms and the messages.
+// ------------------------------------------------------------------------------------------------
+// utils.rs:36-41, but two-sided: the reference's `frac as u32` saturates negative errors to 0
+// (a one-sided error distribution); a negative error wraps mod 2^32 here.
+inline uint32_t f64_to_torus_unsigned_representation(double v) {
+  double frac = v - std::round(v);
+  frac = std::round(frac * 4294967296.0);
+  return static_cast<uint32_t>(static_cast<uint64_t>(static_cast<int64_t>(frac)));
+}
+template <class Rng>
+void sample_uniform_slice(Rng& rng, uint32_t* out, size_t len) {  // utils.rs:56-66
+  std::uniform_int_distribution<uint32_t> d;
+  for (size_t i = 0; i < len; ++i) out[i] = d(rng);
+}
+template <class Rng>
+void sample_gaussian_slice(double std_dev, Rng& rng, uint32_t* out, size_t len) {  // utils.rs:43-54
+  std::normal_distribution<double> d(0.0, std_dev);
+  for (size_t i = 0; i < len; ++i) out[i] = f64_to_torus_unsigned_representation(d(rng));
+}
+template <class Rng>
+void sample_binary_slice(Rng& rng, uint32_t* out, size_t len) {  // utils.rs:68-93
+  std::uniform_int_distribution<unsigned> byte(0, 255);
+  unsigned cur = byte(rng), bit = 0;
+  for (size_t i = 0; i < len; ++i) {
+    out[i] = (cur >> bit) & 1u;
+    if (++bit == 8) {
+      cur = byte(rng);
+      bit = 0;
+    }
+  }
+}
+
+// lwe.rs:47-60
+struct LweSecretKey {
+  std::vector<uint32_t> data;
+  template <class Rng>
+  static LweSecretKey random(size_t lwe_dimension, Rng& rng) {
+    LweSecretKey sk{std::vector<uint32_t>(lwe_dimension)};
+    sample_binary_slice(rng, sk.data.data(), sk.data.size());
+    return sk;
+  }
+};
+// glwe.rs:171-182: (k, N) row-major
+struct GlweSecretKey {
+  std::vector<uint32_t> data;
+  template <class Rng>
+  static GlweSecretKey random(const TfheParams& p, Rng& rng) {
+    GlweSecretKey sk{std::vector<uint32_t>(p.glwe_dimension * p.degree())};
+    sample_binary_slice(rng, sk.data.data(), sk.data.size());
+    return sk;
+  }
+};
+// LweSecretKey::from(&GlweSecretKey) lwe.rs:62-73: the row-major flattening
+inline LweSecretKey lwe_secret_key_from(const GlweSecretKey& sk) { return LweSecretKey{sk.data}; }
+
+// LweCleartext::encode_message lwe.rs:81-92 / LwePlaintext::decode lwe.rs:100-107
+inline uint32_t encode_message(uint32_t m, const TfheParams& p) {
+  if (m >= (1u << p.log_p)) throw TfheError(TFHE_ERR_INVALID_ARGUMENT, "assertion failed: m < 1 << log_p");
+  return m << (p.log_q - (p.log_p + p.padding_bits));
+}
+inline uint32_t decode_plaintext(uint32_t pt, const TfheParams& p) {
+  return pt >> (p.log_q - (p.log_p + p.padding_bits));
+}
+
+// encrypt_lwe_plaintext lwe.rs:138-160 (draw order: error, then mask); `plaintext` is encoded
+template <class Rng>
+LweCiphertext encrypt_lwe_plaintext(Engine& e, double std_dev, const LweSecretKey& sk, uint32_t plaintext,
+                                    Rng& rng) {
+  const size_t n = sk.data.size();
+  LweCiphertext ct{std::vector<uint32_t>(n + 1)};
+  sample_gaussian_slice(std_dev, rng, &ct.data[n], 1);
+  sample_uniform_slice(rng, ct.data.data(), n);
+  e.check(tfhe_lwe_encrypt_batch(e.raw(), sk.data.data(), n, &plaintext, ct.data.data(), 1));
+  return ct;
+}
+// decrypt_lwe lwe.rs:162-173 -> encoded plaintext
+inline uint32_t decrypt_lwe(Engine& e, const LweSecretKey& sk, const LweCiphertext& ct) {
+  uint32_t pt = 0;
+  e.check(tfhe_lwe_decrypt_batch(e.raw(), sk.data.data(), sk.data.size(), ct.data.data(), 1, &pt));
+  return pt;
+}
+
+// encrypt_glwe_zero glwe.rs:190-209 (draw order: masks, then errors)
+template <class Rng>
+void fill_glwe_samples(const TfheParams& p, Rng& rng, uint32_t* row) {
+  const size_t N = p.degree(), k = p.glwe_dimension;
+  sample_uniform_slice(rng, row, k * N);
+  sample_gaussian_slice(p.glwe_std_dev, rng, row + k * N, N);
+}
+template <class Rng>
+GlweCiphertext encrypt_glwe_zero(Engine& e, const GlweSecretKey& sk, Rng& rng) {
+  const TfheParams& p = e.params();
+  GlweCiphertext ct{std::vector<uint32_t>((p.glwe_dimension + 1) * p.degree())};
+  fill_glwe_samples(p, rng, ct.data.data());
+  e.check(tfhe_glwe_encrypt_zero_batch(e.raw(), sk.data.data(), ct.data.data(), 1));
+  return ct;
+}
+// encrypt_glwe_plaintext glwe.rs:211-230: message polynomial (encoded) added to the body
+template <class Rng>
+GlweCiphertext encrypt_glwe_plaintext(Engine& e, const std::vector<uint32_t>& plaintext, const GlweSecretKey& sk,
+                                      Rng& rng) {
+  const TfheParams& p = e.params();
+  if (plaintext.size() != p.degree()) throw TfheError(TFHE_ERR_INVALID_ARGUMENT, "plaintext shape");
+  GlweCiphertext ct = encrypt_glwe_zero(e, sk, rng);
+  uint32_t* body = ct.data.data() + p.glwe_dimension * p.degree();
+  for (size_t i = 0; i < p.degree(); ++i) body[i] += plaintext[i];
+  return ct;
+}
+// decrypt_glwe_ciphertext glwe.rs:245-265 -> encoded plaintext polynomial
+inline std::vector<uint32_t> decrypt_glwe_ciphertext(Engine& e, const GlweSecretKey& sk, const GlweCiphertext& ct) {
+  std::vector<uint32_t> pt(e.params().degree());
+  e.check(tfhe_glwe_decrypt_batch(e.raw(), sk.data.data(), ct.data.data(), 1, pt.data()));
+  return pt;
+}
+// encrypt_ggsw_plaintext ggsw.rs:76-130
+template <class Rng>
+GgswCiphertext encrypt_ggsw_plaintext(Engine& e, uint32_t message, const GlweSecretKey& sk, Rng& rng) {
+  const TfheParams& p = e.params();
+  const size_t row_words = (p.glwe_dimension + 1) * p.degree();
+  GgswCiphertext g{std::vector<uint32_t>(p.ggsw_rows() * row_words)};
+  for (size_t r = 0; r < p.ggsw_rows(); ++r) fill_glwe_samples(p, rng, g.data.data() + r * row_words);
+  e.check(tfhe_ggsw_encrypt_batch(e.raw(), sk.data.data(), &message, g.data.data(), 1));
+  return g;
+}
+// KeySwitchingKey::generate_ksk key_switching.rs:20-60 (the engine's ks_decomposer)
+template <class Rng>
+KeySwitchingKey generate_ksk(Engine& e, const LweSecretKey& from_lwe_sk, const LweSecretKey& to_lwe_sk,
+                             double to_std_dev, Rng& rng) {
+  const size_t to_n = to_lwe_sk.data.size();
+  const size_t rows = from_lwe_sk.data.size() * e.params().ks_decomposer.levels;
+  KeySwitchingKey ksk{std::vector<uint32_t>(rows * (to_n + 1))};
+  for (size_t r = 0; r < rows; ++r) {  // encrypt_lwe_zero lwe.rs:117-136: error, then mask
+    uint32_t* row = ksk.data.data() + r * (to_n + 1);
+    sample_gaussian_slice(to_std_dev, rng, row + to_n, 1);
+    sample_uniform_slice(rng, row, to_n);
+  }
+  e.check(tfhe_generate_ksk(e.raw(), from_lwe_sk.data.data(), from_lwe_sk.data.size(), to_lwe_sk.data.data(),
+                            to_n, ksk.data.data()));
+  return ksk;
+}
+// bootstrapping_key_gen bootstrapping.rs:23-56; the generated key is also installed in the engine
+template <class Rng>
+BootstrappingKey bootstrapping_key_gen(Engine& e, const LweSecretKey& lwe_secret_key,
+                                       const GlweSecretKey& glwe_secret_key, Rng& rng) {
+  const TfheParams& p = e.params();
+  const size_t n = p.lwe_dimension, row_words = (p.glwe_dimension + 1) * p.degree();
+  const size_t ggsw_words = p.ggsw_rows() * row_words;
+  if (lwe_secret_key.data.size() != n) throw TfheError(TFHE_ERR_INVALID_ARGUMENT, "lwe secret key shape");
+  std::vector<uint32_t> bsk(n * ggsw_words);
+  for (size_t r = 0; r < n * p.ggsw_rows(); ++r) fill_glwe_samples(p, rng, bsk.data() + r * row_words);
+  const size_t ks_rows = p.lwe_dimension_post_pbs() * p.ks_decomposer.levels;
+  KeySwitchingKey ksk{std::vector<uint32_t>(ks_rows * (n + 1))};
+  for (size_t r = 0; r < ks_rows; ++r) {
+    uint32_t* row = ksk.data.data() + r * (n + 1);
+    sample_gaussian_slice(p.lwe_std_dev, rng, row + n, 1);
+    sample_uniform_slice(rng, row, n);
+  }
+  e.check(tfhe_bootstrapping_key_gen(e.raw(), lwe_secret_key.data.data(), glwe_secret_key.data.data(), bsk.data(),
+                                     ksk.data.data(), 1));
+  BootstrappingKey bk;
+  bk.lwe_sk_ggsw_enc.reserve(n);
+  for (size_t i = 0; i < n; ++i)
+    bk.lwe_sk_ggsw_enc.push_back(
+        GgswCiphertext{std::vector<uint32_t>(bsk.begin() + i * ggsw_words, bsk.begin() + (i + 1) * ggsw_words)});
+  bk.ksk = std::move(ksk);
+  return bk;
 }
 
 }  // namespace tfhe_amd

@@ -198,6 +198,56 @@ int tfhe_gate_batch(tfhe_context *ctx, const uint32_t truth[4], const uint32_t *
 int tfhe_gate_batch_device(tfhe_context *ctx, const uint32_t truth[4], const uint32_t *ct0,
                            const uint32_t *ct1, size_t batch, uint32_t *lwe_out);
 
+/* ---- encryption side: keygen / encrypt / decrypt --------------------------------
+ * The reference draws its randomness from the caller's `rng: &mut R` (uniform masks with
+ * sample_uniform_array, errors with sample_gaussian_array); the draws stay with the caller here too:
+ * every in/out buffer arrives PRE-FILLED -- mask words hold the uniform samples, the body word /
+ * body polynomial holds the error sample(s) -- and the call turns it into the ciphertext by adding
+ * the <mask, key> term (and the message).  That makes each call a pure function of its arguments,
+ * bit-comparable with the oracle.  Secret keys are host pointers and must be binary (sample_binary,
+ * the only kind the reference generates): other values are refused with TFHE_ERR_INVALID_ARGUMENT. */
+/* encrypt_glwe_zero glwe.rs:190-209: glwe [count][k+1][N] in/out, glwe_sk [k][N];
+ * body += sum_i a_i * s_i.  encrypt_glwe_plaintext (:211-230) = error + message in the body. */
+int tfhe_glwe_encrypt_zero_batch(tfhe_context *ctx, const uint32_t *glwe_sk, uint32_t *glwe,
+                                 size_t count);
+int tfhe_glwe_encrypt_zero_batch_device(tfhe_context *ctx, const uint32_t *glwe_sk, uint32_t *glwe,
+                                        size_t count);
+/* decrypt_glwe_ciphertext glwe.rs:245-265: plaintext_out [count][N] = body - sum_i a_i * s_i */
+int tfhe_glwe_decrypt_batch(tfhe_context *ctx, const uint32_t *glwe_sk, const uint32_t *glwe,
+                            size_t count, uint32_t *plaintext_out);
+/* encrypt_ggsw_plaintext ggsw.rs:76-130 for `count` messages: ggsw [count][(k+1)l][k+1][N] in/out
+ * (every row pre-filled like a GLWE above), messages [count] */
+int tfhe_ggsw_encrypt_batch(tfhe_context *ctx, const uint32_t *glwe_sk, const uint32_t *messages,
+                            uint32_t *ggsw, size_t count);
+int tfhe_ggsw_encrypt_batch_device(tfhe_context *ctx, const uint32_t *glwe_sk,
+                                   const uint32_t *messages /* host */, uint32_t *ggsw, size_t count);
+/* encrypt_lwe_plaintext lwe.rs:138-160 (encrypt_lwe_zero :117-136 with plaintexts == NULL):
+ * lwe [batch][dimension+1] in/out, b += <a, s> + plaintexts[i] (already encoded, lwe.rs:81-90) */
+int tfhe_lwe_encrypt_batch(tfhe_context *ctx, const uint32_t *lwe_sk, size_t dimension,
+                           const uint32_t *plaintexts, uint32_t *lwe, size_t batch);
+int tfhe_lwe_encrypt_batch_device(tfhe_context *ctx, const uint32_t *lwe_sk, size_t dimension,
+                                  const uint32_t *plaintexts /* device or NULL */, uint32_t *lwe,
+                                  size_t batch);
+/* decrypt_lwe lwe.rs:162-173: plaintext_out [batch] = b - <a, s> (still encoded; decode = shift) */
+int tfhe_lwe_decrypt_batch(tfhe_context *ctx, const uint32_t *lwe_sk, size_t dimension,
+                           const uint32_t *lwe, size_t batch, uint32_t *plaintext_out);
+int tfhe_lwe_decrypt_batch_device(tfhe_context *ctx, const uint32_t *lwe_sk, size_t dimension,
+                                  const uint32_t *lwe, size_t batch, uint32_t *plaintext_out);
+/* KeySwitchingKey::generate_ksk key_switching.rs:20-60: ksk [from_dimension*l_ks][to_dimension+1]
+ * in/out pre-filled row by row like an LWE; from_sk [from_dimension], to_sk [to_dimension]; uses
+ * the context's ks_decomposer */
+int tfhe_generate_ksk(tfhe_context *ctx, const uint32_t *from_sk, size_t from_dimension,
+                      const uint32_t *to_sk, size_t to_dimension, uint32_t *ksk);
+/* bootstrapping_key_gen bootstrapping.rs:23-56: bsk [n][(k+1)l][k+1][N] and ksk [kN*l_ks][n+1]
+ * in/out, pre-filled; lwe_sk [n], glwe_sk [k][N] (the KSK goes from the flattened GLWE key
+ * lwe.rs:62-73 to lwe_sk).  `load` != 0 also installs the result as the context's key, without a
+ * round trip through the host for the _device form. */
+int tfhe_bootstrapping_key_gen(tfhe_context *ctx, const uint32_t *lwe_sk, const uint32_t *glwe_sk,
+                               uint32_t *bsk, uint32_t *ksk, int load);
+int tfhe_bootstrapping_key_gen_device(tfhe_context *ctx, const uint32_t *lwe_sk,
+                                      const uint32_t *glwe_sk, uint32_t *bsk, uint32_t *ksk,
+                                      int load);
+
 /* ---- introspection for benchmarks --------------------------------------------------------- */
 /* Time of the blind-rotation kernel of the most recent bootstrap/blind_rotate call, measured with
  * HIP events on the context's stream (milliseconds); negative if none was recorded.  Enable with

@@ -150,6 +150,7 @@ def lib():
         _lib.orc_recompose.restype = C.c_uint32
         _lib.orc_integer_division.restype = C.c_uint32
         _lib.orc_decrypt_lwe.restype = C.c_uint32
+        _lib.orc_sample_gaussian.restype = C.c_uint32
         _lib.orc_lwe_decode.restype = C.c_uint32
         _lib.orc_rng_next_u64.restype = C.c_uint64
         _lib.orc_rng_next_u32.restype = C.c_uint32
@@ -455,6 +456,82 @@ def encrypt_ggsw(params: Params, glwe_sk, message: int, rng: Rng) -> np.ndarray:
     set_poly_mul_mode(1)
     lib().orc_encrypt_ggsw_plaintext(C.byref(cp), C.c_uint32(message), _p(sk), C.byref(rng.c), _p(out))
     set_poly_mul_mode(prev)
+    return out
+
+
+# ---- the same with the random draws hoisted out (buffers arrive pre-filled with masks + errors)
+def _schoolbook(fn):
+    prev = lib().orc_get_poly_mul_mode()
+    set_poly_mul_mode(1)
+    try:
+        fn()
+    finally:
+        set_poly_mul_mode(prev)
+
+
+def encrypt_lwe_from_samples(sk, samples, plaintexts=None) -> np.ndarray:
+    """samples [B][n+1]: uniform masks + error in the b slot -> ciphertexts (lwe.rs:138-160)."""
+    sk = _a(sk)
+    out = _a(samples).copy().reshape(-1, sk.size + 1)
+    for i in range(out.shape[0]):
+        pt = 0 if plaintexts is None else int(plaintexts[i])
+        lib().orc_encrypt_lwe_from_samples(C.c_size_t(sk.size), _p(sk), C.c_uint32(pt), _p(out[i]))
+    return out
+
+
+def encrypt_glwe_zero_from_samples(params: Params, sk, samples) -> np.ndarray:
+    """samples [count][k+1][N]: uniform masks + errors in the body (glwe.rs:190-209)."""
+    sk = _a(sk)
+    cp = params.to_c()
+    out = _a(samples).copy().reshape(-1, params.k + 1, params.N)
+    _schoolbook(lambda: [lib().orc_encrypt_glwe_zero_from_samples(C.byref(cp), _p(sk), _p(out[i]))
+                         for i in range(out.shape[0])])
+    return out
+
+
+def encrypt_ggsw_from_samples(params: Params, glwe_sk, messages, samples) -> np.ndarray:
+    """samples [count][R][k+1][N] pre-filled row by row (ggsw.rs:76-130)."""
+    sk = _a(glwe_sk)
+    cp = params.to_c()
+    out = _a(samples).copy().reshape(-1, params.R, params.k + 1, params.N)
+    _schoolbook(lambda: [lib().orc_encrypt_ggsw_from_samples(C.byref(cp), C.c_uint32(int(messages[i])),
+                                                             _p(sk), _p(out[i]))
+                         for i in range(out.shape[0])])
+    return out
+
+
+def generate_ksk_from_samples(from_sk, to_sk, dec: Decomposer, samples) -> np.ndarray:
+    """samples [from_n*levels][to_n+1] pre-filled (key_switching.rs:20-60)."""
+    from_sk, to_sk = _a(from_sk).reshape(-1), _a(to_sk)
+    out = _a(samples).copy()
+    cd = dec.to_c()
+    lib().orc_generate_ksk_from_samples(_p(from_sk), C.c_size_t(from_sk.size), _p(to_sk),
+                                        C.c_size_t(to_sk.size), C.byref(cd), _p(out))
+    return out
+
+
+def bootstrapping_key_gen_from_samples(params: Params, lwe_sk, glwe_sk, bsk_samples, ksk_samples):
+    """bootstrapping.rs:23-56 on pre-filled bsk / ksk buffers -> (bsk, ksk)."""
+    lwe_sk, glwe_sk = _a(lwe_sk), _a(glwe_sk)
+    cp = params.to_c()
+    bsk, ksk = _a(bsk_samples).copy(), _a(ksk_samples).copy()
+    _schoolbook(lambda: lib().orc_bootstrapping_key_gen_from_samples(C.byref(cp), _p(lwe_sk), _p(glwe_sk),
+                                                                    _p(bsk), _p(ksk)))
+    return bsk, ksk
+
+
+def sample_binary(rng: Rng, shape) -> np.ndarray:
+    out = np.zeros(shape, dtype=np.uint32)
+    lib().orc_sample_binary(C.byref(rng.c), _p(out), C.c_size_t(out.size))
+    return out
+
+
+def sample_gaussian(rng: Rng, std_dev: float, shape) -> np.ndarray:
+    out = np.zeros(shape, dtype=np.uint32)
+    flat = out.reshape(-1)
+    fn = lib().orc_sample_gaussian
+    for i in range(flat.size):
+        flat[i] = fn(C.byref(rng.c), C.c_double(std_dev))
     return out
 
 

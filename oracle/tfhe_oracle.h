@@ -187,6 +187,19 @@ void orc_generate_ksk(const uint32_t *from_sk, size_t from_n, const uint32_t *to
 void orc_bootstrapping_key_gen(const orc_params *p, const uint32_t *lwe_sk,
                                const uint32_t *glwe_sk, orc_rng *r, uint32_t *bsk, uint32_t *ksk);
 
+/* The same functions with the random draws hoisted out: the output buffer arrives pre-filled with
+ * the uniform mask words and, in every body slot, the error sample (what the reference draws at
+ * glwe.rs:195,200 / lwe.rs:122-126,143-147); the call is then a pure function of its arguments.
+ * Used to check the GPU keygen / encryption entry points bit for bit. */
+void orc_encrypt_lwe_from_samples(size_t n, const uint32_t *sk, uint32_t pt, uint32_t *ct);
+void orc_encrypt_glwe_zero_from_samples(const orc_params *p, const uint32_t *sk, uint32_t *ct);
+void orc_encrypt_ggsw_from_samples(const orc_params *p, uint32_t message, const uint32_t *glwe_sk,
+                                   uint32_t *ggsw);
+void orc_generate_ksk_from_samples(const uint32_t *from_sk, size_t from_n, const uint32_t *to_sk,
+                                   size_t to_n, const orc_decomposer *d, uint32_t *ksk);
+void orc_bootstrapping_key_gen_from_samples(const orc_params *p, const uint32_t *lwe_sk,
+                                            const uint32_t *glwe_sk, uint32_t *bsk, uint32_t *ksk);
+
 /* sizes (in u32 words) */
 size_t orc_ggsw_words(const orc_params *p);
 size_t orc_bsk_words(const orc_params *p);

@@ -106,15 +106,23 @@ static uint32_t dot_u32(const uint32_t *a, const uint32_t *b, size_t n) {
     return acc;
 }
 
-/* lwe.rs:138-160 (encrypt_lwe_zero :117-136 is the pt = 0 case) */
-void orc_encrypt_lwe_plaintext(size_t n, double std_dev, const uint32_t *sk, uint32_t pt,
-                               orc_rng *r, uint32_t *ct) {
-    uint32_t error = orc_sample_gaussian(r, std_dev);
-    orc_fill_uniform_u32(r, ct, n);
+/* lwe.rs:138-160 with the draws hoisted out: ct[0..n) already holds the uniform mask, ct[n] the
+ * error sample; b = <s, a> + error + pt */
+void orc_encrypt_lwe_from_samples(size_t n, const uint32_t *sk, uint32_t pt, uint32_t *ct) {
+    uint32_t error = ct[n];
     uint32_t a_s = dot_u32(sk, ct, n);
     a_s += error;
     a_s += pt;
     ct[n] = a_s;
+}
+
+/* lwe.rs:138-160 (encrypt_lwe_zero :117-136 is the pt = 0 case); draw order: error, then mask */
+void orc_encrypt_lwe_plaintext(size_t n, double std_dev, const uint32_t *sk, uint32_t pt,
+                               orc_rng *r, uint32_t *ct) {
+    uint32_t error = orc_sample_gaussian(r, std_dev);
+    orc_fill_uniform_u32(r, ct, n);
+    ct[n] = error;
+    orc_encrypt_lwe_from_samples(n, sk, pt, ct);
 }
 
 /* lwe.rs:162-173 */
@@ -122,14 +130,26 @@ uint32_t orc_decrypt_lwe(size_t n, const uint32_t *sk, const uint32_t *ct) {
     return ct[n] - dot_u32(sk, ct, n);
 }
 
-/* glwe.rs:190-209 */
+/* glwe.rs:190-209 with the draws hoisted out: the k mask polynomials of ct already hold the
+ * uniform samples, the body polynomial the error samples; body = sum a_i * s_i + error */
+void orc_encrypt_glwe_zero_from_samples(const orc_params *p, const uint32_t *sk, uint32_t *ct) {
+    size_t n = degree_of(p);
+    size_t k = p->glwe_dimension;
+    uint32_t *body = ct + k * n;
+    uint32_t *a_s = (uint32_t *)malloc(n * sizeof(uint32_t));
+    orc_poly_dot_product(ct, sk, n, k, n, a_s);
+    for (size_t i = 0; i < n; ++i) body[i] += a_s[i];
+    free(a_s);
+}
+
+/* glwe.rs:190-209; draw order: masks, then errors */
 void orc_encrypt_glwe_zero(const orc_params *p, const uint32_t *sk, orc_rng *r, uint32_t *ct) {
     size_t n = degree_of(p);
     size_t k = p->glwe_dimension;
     orc_fill_uniform_u32(r, ct, k * n);
     uint32_t *body = ct + k * n;
-    orc_poly_dot_product(ct, sk, n, k, n, body);
-    for (size_t i = 0; i < n; ++i) body[i] += orc_sample_gaussian(r, p->glwe_std_dev);
+    for (size_t i = 0; i < n; ++i) body[i] = orc_sample_gaussian(r, p->glwe_std_dev);
+    orc_encrypt_glwe_zero_from_samples(p, sk, ct);
 }
 
 /* glwe.rs:211-230 */
@@ -155,8 +175,8 @@ void orc_decrypt_glwe_ciphertext(const orc_params *p, const uint32_t *sk, const 
 /* ggsw.rs:76-130: row = poly_index*levels + level is a GLWE encryption of zero with
  * message * 2^{log_base*(floor(log_q/log_base) - (level+1))} added to coefficient 0 of
  * polynomial `poly_index` (:96-103); nothing is added when message == 0 */
-void orc_encrypt_ggsw_plaintext(const orc_params *p, uint32_t message, const uint32_t *glwe_sk,
-                                orc_rng *r, uint32_t *ggsw) {
+static void ggsw_rows(const orc_params *p, uint32_t message, const uint32_t *glwe_sk, orc_rng *r,
+                      uint32_t *ggsw) {
     size_t n = degree_of(p);
     size_t k1 = p->glwe_dimension + 1;
     const orc_decomposer *d = &p->pbs_decomposer;
@@ -164,7 +184,8 @@ void orc_encrypt_ggsw_plaintext(const orc_params *p, uint32_t message, const uin
     for (size_t i = 0; i < k1; ++i) {
         for (uint32_t level_index = 0; level_index < d->levels; ++level_index) {
             uint32_t *row = ggsw + (i * d->levels + level_index) * k1 * n;
-            orc_encrypt_glwe_zero(p, glwe_sk, r, row);
+            if (r) orc_encrypt_glwe_zero(p, glwe_sk, r, row);
+            else orc_encrypt_glwe_zero_from_samples(p, glwe_sk, row);
             if (message != 0) {
                 uint32_t decomposition_factor =
                     message * ((uint32_t)1 << (d->log_base * (log_q_by_log_base - (level_index + 1))));
@@ -174,20 +195,43 @@ void orc_encrypt_ggsw_plaintext(const orc_params *p, uint32_t message, const uin
     }
 }
 
+void orc_encrypt_ggsw_plaintext(const orc_params *p, uint32_t message, const uint32_t *glwe_sk,
+                                orc_rng *r, uint32_t *ggsw) {
+    ggsw_rows(p, message, glwe_sk, r, ggsw);
+}
+
+/* the same with every row pre-filled (masks + errors) by the caller */
+void orc_encrypt_ggsw_from_samples(const orc_params *p, uint32_t message, const uint32_t *glwe_sk,
+                                   uint32_t *ggsw) {
+    ggsw_rows(p, message, glwe_sk, NULL, ggsw);
+}
+
 /* key_switching.rs:20-60: row s_index*levels + level = LWE_to(0) with
  * s_bit * 2^{log_base*(l - (level+1))} added to the b slot */
-void orc_generate_ksk(const uint32_t *from_sk, size_t from_n, const uint32_t *to_sk, size_t to_n,
-                      double to_std_dev, const orc_decomposer *d, orc_rng *r, uint32_t *ksk) {
+static void ksk_rows(const uint32_t *from_sk, size_t from_n, const uint32_t *to_sk, size_t to_n,
+                     double to_std_dev, const orc_decomposer *d, orc_rng *r, uint32_t *ksk) {
     uint32_t l = d->log_q / d->log_base;
     for (size_t s_index = 0; s_index < from_n; ++s_index) {
         for (uint32_t level_index = 0; level_index < d->levels; ++level_index) {
             uint32_t factor = (uint32_t)1 << (d->log_base * (l - (level_index + 1)));
             factor *= from_sk[s_index];
             uint32_t *row = ksk + (s_index * d->levels + level_index) * (to_n + 1);
-            orc_encrypt_lwe_plaintext(to_n, to_std_dev, to_sk, 0u, r, row);
+            if (r) orc_encrypt_lwe_plaintext(to_n, to_std_dev, to_sk, 0u, r, row);
+            else orc_encrypt_lwe_from_samples(to_n, to_sk, 0u, row);
             row[to_n] += factor;
         }
     }
+}
+
+void orc_generate_ksk(const uint32_t *from_sk, size_t from_n, const uint32_t *to_sk, size_t to_n,
+                      double to_std_dev, const orc_decomposer *d, orc_rng *r, uint32_t *ksk) {
+    ksk_rows(from_sk, from_n, to_sk, to_n, to_std_dev, d, r, ksk);
+}
+
+/* the same with every row pre-filled (mask + error in the b slot) by the caller */
+void orc_generate_ksk_from_samples(const uint32_t *from_sk, size_t from_n, const uint32_t *to_sk,
+                                   size_t to_n, const orc_decomposer *d, uint32_t *ksk) {
+    ksk_rows(from_sk, from_n, to_sk, to_n, 0.0, d, NULL, ksk);
 }
 
 /* bootstrapping.rs:23-56 */
@@ -202,4 +246,15 @@ void orc_bootstrapping_key_gen(const orc_params *p, const uint32_t *lwe_sk,
      * glwe_sk buffer itself viewed as k*N words */
     orc_generate_ksk(glwe_sk, n * p->glwe_dimension, lwe_sk, p->lwe_dimension, p->lwe_std_dev,
                      &p->ks_decomposer, r, ksk);
+}
+
+/* bootstrapping.rs:23-56 with bsk and ksk pre-filled (masks + errors) by the caller */
+void orc_bootstrapping_key_gen_from_samples(const orc_params *p, const uint32_t *lwe_sk,
+                                            const uint32_t *glwe_sk, uint32_t *bsk, uint32_t *ksk) {
+    size_t n = degree_of(p);
+    size_t ggsw_len = orc_ggsw_words(p);
+    for (size_t i = 0; i < p->lwe_dimension; ++i)
+        orc_encrypt_ggsw_from_samples(p, lwe_sk[i], glwe_sk, bsk + i * ggsw_len);
+    orc_generate_ksk_from_samples(glwe_sk, n * p->glwe_dimension, lwe_sk, p->lwe_dimension,
+                                  &p->ks_decomposer, ksk);
 }

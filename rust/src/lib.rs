@@ -9,6 +9,7 @@
 //!   external_product     ggsw.rs:132-136        cmux   ggsw.rs:164-169
 //!   and / or             boolean.rs:9-14, 32-37
 //!   construct_test_from_lut  test_vector.rs:38
+//!   bootstrapping_key_gen    bootstrapping.rs:23-28   encrypt_lwe_plaintext / decrypt_lwe  lwe.rs:138-173
 use ndarray::{Array1, Array2, Array3};
 use std::os::raw::{c_char, c_int, c_void};
 
@@ -43,6 +44,12 @@ extern "C" {
     fn tfhe_construct_test_from_lut(params: *const CTfheParams, lut: *const u32, lut_len: usize, out: *mut u32) -> c_int;
     #[allow(dead_code)]
     fn tfhe_context_set_stream(ctx: *mut TfheContext, hip_stream: *mut c_void) -> c_int;
+    fn tfhe_bootstrapping_key_gen(ctx: *mut TfheContext, lwe_sk: *const u32, glwe_sk: *const u32,
+                                  bsk: *mut u32, ksk: *mut u32, load: c_int) -> c_int;
+    fn tfhe_lwe_encrypt_batch(ctx: *mut TfheContext, lwe_sk: *const u32, dimension: usize,
+                              plaintexts: *const u32, lwe: *mut u32, batch: usize) -> c_int;
+    fn tfhe_lwe_decrypt_batch(ctx: *mut TfheContext, lwe_sk: *const u32, dimension: usize,
+                              lwe: *const u32, batch: usize, plaintext_out: *mut u32) -> c_int;
 }
 
 /// The reference panics on failure (assert!/unwrap); so does this shim -- but only on the Rust
@@ -140,5 +147,46 @@ pub fn construct_test_from_lut(params: &CTfheParams, lut: &[u32]) -> Array1<u32>
     let mut out = Array1::<u32>::zeros(1usize << params.glwe_poly_degree);
     let st = unsafe { tfhe_construct_test_from_lut(params, lut.as_ptr(), lut.len(), out.as_slice_mut().unwrap().as_mut_ptr()) };
     assert!(st == 0, "lut must hold 2^log_p entries (test_vector.rs:41)");
+    out
+}
+
+/// bootstrapping_key_gen (bootstrapping.rs:23-28) on the GPU.  The crate keeps drawing the
+/// randomness with its own `rng` -- `bsk_samples` ((n, (k+1)l, k+1, N): `sample_uniform_array`
+/// masks, `sample_gaussian_array` errors in every body row, glwe.rs:195,200) and `ksk_samples`
+/// ((kN*l_ks, n+1): masks + the error in the b slot, lwe.rs:122-126) -- and the engine turns the
+/// buffers into the key in place and installs it.
+pub fn bootstrapping_key_gen(params: CTfheParams, lwe_secret_key: &Array1<u32>, glwe_secret_key: &Array2<u32>,
+                             mut bsk_samples: ndarray::Array4<u32>, mut ksk_samples: Array2<u32>)
+                             -> (GpuBootstrappingKey, ndarray::Array4<u32>, Array2<u32>) {
+    let mut ctx = std::ptr::null_mut();
+    let st = unsafe { tfhe_context_create(&params, 0, &mut ctx) };
+    assert!(st == 0, "tfhe_context_create: status {st}");
+    check(ctx, unsafe {
+        tfhe_bootstrapping_key_gen(ctx, lwe_secret_key.as_slice().unwrap().as_ptr(),
+                                   glwe_secret_key.as_slice().unwrap().as_ptr(),
+                                   bsk_samples.as_slice_mut().unwrap().as_mut_ptr(),
+                                   ksk_samples.as_slice_mut().unwrap().as_mut_ptr(), 1)
+    }, "bootstrapping_key_gen");
+    (GpuBootstrappingKey { ctx, params }, bsk_samples, ksk_samples)
+}
+
+/// encrypt_lwe_plaintext (lwe.rs:138-160) over a batch: `samples` (batch, n+1) holds the uniform
+/// masks and, in the b slot, the error; `plaintexts` are encoded (lwe.rs:81-92).
+pub fn encrypt_lwe_batch(bk: &GpuBootstrappingKey, sk: &Array1<u32>, plaintexts: &Array1<u32>, mut samples: Array2<u32>) -> Array2<u32> {
+    let batch = samples.nrows();
+    check(bk.ctx, unsafe {
+        tfhe_lwe_encrypt_batch(bk.ctx, sk.as_slice().unwrap().as_ptr(), sk.len(), plaintexts.as_slice().unwrap().as_ptr(),
+                               samples.as_slice_mut().unwrap().as_mut_ptr(), batch)
+    }, "encrypt_lwe_batch");
+    samples
+}
+
+/// decrypt_lwe (lwe.rs:162-173) over a batch -> encoded plaintexts
+pub fn decrypt_lwe_batch(bk: &GpuBootstrappingKey, sk: &Array1<u32>, cts: &Array2<u32>) -> Array1<u32> {
+    let mut out = Array1::<u32>::zeros(cts.nrows());
+    check(bk.ctx, unsafe {
+        tfhe_lwe_decrypt_batch(bk.ctx, sk.as_slice().unwrap().as_ptr(), sk.len(), cts.as_slice().unwrap().as_ptr(),
+                               cts.nrows(), out.as_slice_mut().unwrap().as_mut_ptr())
+    }, "decrypt_lwe_batch");
     out
 }

@@ -4,6 +4,7 @@
 // bit-exact expected values.
 #include <cstdio>
 #include <cstring>
+#include <random>
 #include <vector>
 
 #include "tfhe.hpp"
@@ -127,6 +128,64 @@ int main() {
     orc_decompose(&op.pbs_decomposer, 0xABCDEF12u, legs);
     auto got = dec.decompose(0xABCDEF12u);
     EXPECT(got.size() == op.pbs_decomposer.levels && std::memcmp(got.data(), legs, got.size() * 4) == 0, "decompose");
+  }
+  // The same flows with keys and ciphertexts made by the mirror itself (GPU keygen / encryption,
+  // randomness from a C++ engine in place of the reference's thread_rng): bootstrapping_works,
+  // key_switching_works (key_switching.rs:118-159), ggsw external_product_works (ggsw.rs:203-240)
+  {
+    std::mt19937_64 gen(20261003);
+    Engine e2(tfhe_params);
+    LweSecretKey lwe_secret_key = LweSecretKey::random(n, gen);
+    GlweSecretKey glwe_secret_key = GlweSecretKey::random(tfhe_params, gen);
+    BootstrappingKey bk = bootstrapping_key_gen(e2, lwe_secret_key, glwe_secret_key, gen);
+    EXPECT(bk.lwe_sk_ggsw_enc.size() == n && bk.ksk.data.size() == ksk.size(), "generated key shapes");
+    // every GGSW of the generated key decrypts to gadget rows of its key bit: row (i, level) body
+    // minus <masks, s> has message*2^{32-logB*(level+1)} on coefficient 0 of column i == k
+    const uint32_t logB = tfhe_params.pbs_decomposer.log_base, L = tfhe_params.pbs_decomposer.levels;
+    for (size_t bit = 0; bit < n; ++bit) {
+      const auto& g = bk.lwe_sk_ggsw_enc[bit].data;
+      const size_t row_words = (k + 1) * N;
+      GlweCiphertext last_row{std::vector<uint32_t>(g.begin() + (k * L) * row_words, g.begin() + (k * L + 1) * row_words)};
+      auto pt = decrypt_glwe_ciphertext(e2, glwe_secret_key, last_row);
+      const uint32_t want = lwe_secret_key.data[bit] << (logB * (32 / logB - 1));
+      const int32_t err = (int32_t)(pt[0] - want);
+      EXPECT(err > -(1 << 12) && err < (1 << 12), "GGSW body row decrypts to s_i * B^{l-1} + small error");
+    }
+    auto test_vector_poly = construct_identity_test_vector(tfhe_params);
+    auto dec_msg = [&](const LweCiphertext& ct) {
+      uint32_t raw = decrypt_lwe(e2, lwe_secret_key, ct);
+      return decode_plaintext(raw + (1u << (32 - tfhe_params.log_p - tfhe_params.padding_bits - 1)), tfhe_params) & 3u;
+    };
+    for (uint32_t m = 0; m < 4; ++m) {
+      LweCiphertext ct = encrypt_lwe_plaintext(e2, tfhe_params.lwe_std_dev, lwe_secret_key,
+                                               encode_message(m, tfhe_params), gen);
+      EXPECT(dec_msg(ct) == m, "encrypt/decrypt round trip");
+      EXPECT(dec_msg(bootstrap(e2, ct, test_vector_poly)) == m, "bootstrapping_works with generated keys");
+      // key_switching_works: encrypt under the flattened GLWE key, switch, decrypt under the LWE key
+      LweSecretKey big = lwe_secret_key_from(glwe_secret_key);
+      LweCiphertext big_ct = encrypt_lwe_plaintext(e2, tfhe_params.lwe_std_dev, big, encode_message(m, tfhe_params), gen);
+      EXPECT(dec_msg(key_switch_lwe(e2, big_ct)) == m, "key_switching_works with generated keys");
+    }
+    // external_product_works: GGSW(m1) x GLWE(m2) decrypts to m1*m2 (m1 a bit)
+    for (uint32_t m1 = 0; m1 < 2; ++m1) {
+      GgswCiphertext ggsw = encrypt_ggsw_plaintext(e2, m1, glwe_secret_key, gen);
+      std::vector<uint32_t> msg(N);
+      for (size_t i = 0; i < N; ++i) msg[i] = encode_message((uint32_t)(i & 3u), tfhe_params);
+      GlweCiphertext glwe = encrypt_glwe_plaintext(e2, msg, glwe_secret_key, gen);
+      auto pt = decrypt_glwe_ciphertext(e2, glwe_secret_key, external_product(e2, ggsw, glwe));
+      bool ok = true;
+      for (size_t i = 0; i < N; ++i) {
+        const uint32_t got = decode_plaintext(pt[i] + (1u << (32 - tfhe_params.log_p - tfhe_params.padding_bits - 1)), tfhe_params) & 3u;
+        ok = ok && got == (m1 ? (uint32_t)(i & 3u) : 0u);
+      }
+      EXPECT(ok, "external_product_works with generated GGSW/GLWE");
+    }
+    bool threw = false;
+    try {
+      LweSecretKey bad{std::vector<uint32_t>(n, 2u)};
+      encrypt_lwe_plaintext(e2, 1e-5, bad, 0u, gen);
+    } catch (const TfheError&) { threw = true; }
+    EXPECT(threw, "non-binary secret key refused");
   }
   // error behaviour: the reference panics, the mirror throws
   {

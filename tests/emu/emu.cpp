@@ -130,6 +130,22 @@ void ext_product(const PbsParams& P, const typename F::elem* ggsw, const u32* gl
   });
 }
 
+// body_out = body_in +/- sum_i masks[i] (*) sk[i] for `rows` GLWE rows [k+1][N]
+template <class F, int LOGN, int G>
+void glwe_body(u32 k, size_t rows, const u32* glwe, const u32* sk, u32* out, int negate) {
+  typedef typename F::elem elem;
+  constexpr int N = 1 << LOGN;
+  const elem n_inv = F::n_inv(LOGN);
+  run_team<F>(LOGN, 1, G, [&](const HostWave<elem>& w) {
+    for (size_t row = 0; row < rows; ++row) {
+      const u32* masks = glwe + row * (size_t)(k + 1) * N;
+      const u32* body = masks + (size_t)k * N;
+      auto dst = [&](int j, u32 dot) { out[row * N + j] = negate ? body[j] - dot : body[j] + dot; };
+      glwe_mask_dot_key<F, LOGN, G>(w, k, masks, sk, n_inv, dst);
+    }
+  });
+}
+
 PbsParams make_params(u32 n, u32 k, u32 log_n, u32 log_p, u32 padding, u32 log_base, u32 levels) {
   PbsParams P;
   P.n = n;
@@ -215,6 +231,12 @@ int emu_external_product(int field, int g, u32 k, u32 logn, u32 log_base, u32 le
   if (k == 1) { DISPATCH_FIELD(field, DISPATCH_LOGN(logn, g, (ext_product<FF, L, 1, GG>(P, (const FF::elem*)ggsw, glwe, out)))); }
   else if (k == 2) { DISPATCH_FIELD(field, DISPATCH_LOGN(logn, g, (ext_product<FF, L, 2, GG>(P, (const FF::elem*)ggsw, glwe, out)))); }
   else return 2;
+  return 0;
+}
+
+int emu_glwe_body(int field, int logn, int g, u32 k, size_t rows, const u32* glwe, const u32* sk, u32* out,
+                  int negate) {
+  DISPATCH_FIELD(field, DISPATCH_LOGN(logn, g, (glwe_body<FF, L, GG>(k, rows, glwe, sk, out, negate))));
   return 0;
 }
 

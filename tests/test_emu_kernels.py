@@ -265,3 +265,32 @@ def test_wide_base_needs_split_goldilocks(emu, oracle):
     out = np.zeros_like(glwe)
     assert emu.emu_external_product(GLS, 2, 1, 11, 23, 1, p64(spec), p32(glwe), p32(out)) == 0
     assert np.array_equal(out, oracle.external_product(params, ggsw, glwe))
+
+
+# ---------------------------------------------------------------- encryption side
+@pytest.mark.parametrize("field", FIELDS)
+@pytest.mark.parametrize("k,logn,g", [(1, 9, 1), (2, 9, 1), (1, 10, 1), (2, 11, 1), (2, 11, 2)])
+def test_glwe_mask_dot_key_vs_oracle(emu, oracle, field, k, logn, g):
+    """glwe_mask_dot_key (the a*s of glwe.rs:197/:252) against the oracle's encrypt_glwe_zero /
+    decrypt_glwe_ciphertext with the same pre-drawn samples; includes the all-ones key and
+    all-0xFFFFFFFF / 0x8000 / 0x7FFF mask halves that maximise the convolution."""
+    params = oracle.Params(k, logn, 16, oracle.Decomposer(4, 3))
+    N = params.N
+    rng = np.random.default_rng(5 * logn + k + 100 * g)
+    rows = 3
+    samples = rng.integers(0, 1 << 32, size=(rows, k + 1, N), dtype=np.uint64).astype(np.uint32)
+    samples[1, :k] = 0xFFFFFFFF
+    samples[2, :k, ::2] = 0x80008000
+    samples[2, :k, 1::2] = 0x7FFF7FFF
+    for sk in (rng.integers(0, 2, size=(k, N), dtype=np.uint64).astype(np.uint32),
+               np.ones((k, N), dtype=np.uint32)):
+        out = np.zeros((rows, N), dtype=np.uint32)
+        assert emu.emu_glwe_body(field, logn, g, k, rows, p32(samples), p32(sk), p32(out), 0) == 0
+        expect = oracle.encrypt_glwe_zero_from_samples(params, sk, samples)
+        assert np.array_equal(out, expect[:, k])
+        assert np.array_equal(expect[:, :k], samples[:, :k])   # masks untouched
+        dec = np.zeros((rows, N), dtype=np.uint32)
+        assert emu.emu_glwe_body(field, logn, g, k, rows, p32(expect), p32(sk), p32(dec), 1) == 0
+        assert np.array_equal(dec, samples[:, k])              # decrypt gives the error samples back
+        for r in range(rows):
+            assert np.array_equal(dec[r], oracle.decrypt_glwe_raw(params, sk, expect[r]))

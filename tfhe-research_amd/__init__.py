@@ -25,6 +25,8 @@ STATUS_NAMES = {
     0: "TFHE_OK", 1: "TFHE_ERR_INVALID_PARAMS", 2: "TFHE_ERR_UNSUPPORTED", 3: "TFHE_ERR_NO_KEY",
     4: "TFHE_ERR_HIP", 5: "TFHE_ERR_INVALID_ARGUMENT", 6: "TFHE_ERR_NO_DEVICE", 7: "TFHE_ERR_EXACTNESS",
 }
+(TFHE_ERR_INVALID_PARAMS, TFHE_ERR_UNSUPPORTED, TFHE_ERR_NO_KEY, TFHE_ERR_HIP, TFHE_ERR_INVALID_ARGUMENT,
+ TFHE_ERR_NO_DEVICE, TFHE_ERR_EXACTNESS) = range(1, 8)
 DECOMPOSER_PBS, DECOMPOSER_KS = 0, 1
 BACKEND_AUTO, BACKEND_GOLDILOCKS, BACKEND_FP64, BACKEND_GOLDILOCKS_SPLIT = 0, 1, 2, 3
 
@@ -458,3 +460,105 @@ class Context:
         res = np.zeros_like(a)
         self._check(lib().tfhe_gate_batch(self._h, arr, _hp(a), _hp(b), C.c_size_t(a.shape[0]), _hp(res)))
         return res
+
+    # -- encryption side: the caller's random draws arrive in the buffers --------
+    def glwe_encrypt_zero(self, glwe_sk, samples):
+        """encrypt_glwe_zero glwe.rs:190-209: samples [count][k+1][N] (uniform masks, errors in the
+        body) -> ciphertexts.  A torch device tensor is completed in place and returned."""
+        p = self.params
+        sk = _np(glwe_sk).reshape(p.k, p.N)
+        if _is_torch(samples):
+            assert tuple(samples.shape[-2:]) == (p.k + 1, p.N)
+            self._check(lib().tfhe_glwe_encrypt_zero_batch_device(
+                self._h, _hp(sk), _dp(samples), C.c_size_t(samples.numel() // ((p.k + 1) * p.N))))
+            return samples
+        out = _np(samples).copy().reshape(-1, p.k + 1, p.N)
+        self._check(lib().tfhe_glwe_encrypt_zero_batch(self._h, _hp(sk), _hp(out), C.c_size_t(out.shape[0])))
+        return out
+
+    def glwe_decrypt(self, glwe_sk, glwe) -> np.ndarray:
+        """decrypt_glwe_ciphertext glwe.rs:245-265 -> plaintext polynomials [count][N]."""
+        p = self.params
+        sk = _np(glwe_sk).reshape(p.k, p.N)
+        g = _np(glwe).reshape(-1, p.k + 1, p.N)
+        out = np.zeros((g.shape[0], p.N), dtype=np.uint32)
+        self._check(lib().tfhe_glwe_decrypt_batch(self._h, _hp(sk), _hp(g), C.c_size_t(g.shape[0]), _hp(out)))
+        return out
+
+    def ggsw_encrypt(self, glwe_sk, messages, samples):
+        """encrypt_ggsw_plaintext ggsw.rs:76-130 for messages [count]: samples
+        [count][(k+1)l][k+1][N] pre-filled row by row."""
+        p = self.params
+        sk = _np(glwe_sk).reshape(p.k, p.N)
+        msg = _np(messages).reshape(-1)
+        if _is_torch(samples):
+            assert samples.numel() == msg.size * p.R * (p.k + 1) * p.N
+            self._check(lib().tfhe_ggsw_encrypt_batch_device(self._h, _hp(sk), _hp(msg), _dp(samples),
+                                                             C.c_size_t(msg.size)))
+            return samples
+        out = _np(samples).copy().reshape(msg.size, p.R, p.k + 1, p.N)
+        self._check(lib().tfhe_ggsw_encrypt_batch(self._h, _hp(sk), _hp(msg), _hp(out), C.c_size_t(msg.size)))
+        return out
+
+    def lwe_encrypt(self, lwe_sk, samples, plaintexts=None):
+        """encrypt_lwe_plaintext lwe.rs:138-160: samples [batch][dim+1] (uniform masks, error in
+        the b slot), plaintexts [batch] already encoded (None = encrypt_lwe_zero)."""
+        sk = _np(lwe_sk).reshape(-1)
+        dim = sk.size
+        if _is_torch(samples):
+            assert samples.shape[-1] == dim + 1
+            self._check(lib().tfhe_lwe_encrypt_batch_device(
+                self._h, _hp(sk), C.c_size_t(dim), _dp(plaintexts) if plaintexts is not None else None,
+                _dp(samples), C.c_size_t(samples.numel() // (dim + 1))))
+            return samples
+        out = _np(samples).copy().reshape(-1, dim + 1)
+        pt = _np(plaintexts).reshape(-1) if plaintexts is not None else None
+        assert pt is None or pt.size == out.shape[0]
+        self._check(lib().tfhe_lwe_encrypt_batch(self._h, _hp(sk), C.c_size_t(dim),
+                                                 _hp(pt) if pt is not None else None, _hp(out),
+                                                 C.c_size_t(out.shape[0])))
+        return out
+
+    def lwe_decrypt(self, lwe_sk, lwe, out=None):
+        """decrypt_lwe lwe.rs:162-173 -> encoded plaintexts [batch] = b - <a, s>."""
+        sk = _np(lwe_sk).reshape(-1)
+        dim = sk.size
+        if _is_torch(lwe):
+            import torch
+            batch = lwe.numel() // (dim + 1)
+            if out is None:
+                out = torch.empty(batch, dtype=lwe.dtype, device=lwe.device)
+            self._check(lib().tfhe_lwe_decrypt_batch_device(self._h, _hp(sk), C.c_size_t(dim), _dp(lwe),
+                                                            C.c_size_t(batch), _dp(out)))
+            return out
+        rows = _np(lwe).reshape(-1, dim + 1)
+        res = np.zeros(rows.shape[0], dtype=np.uint32)
+        self._check(lib().tfhe_lwe_decrypt_batch(self._h, _hp(sk), C.c_size_t(dim), _hp(rows),
+                                                 C.c_size_t(rows.shape[0]), _hp(res)))
+        return res
+
+    def generate_ksk(self, from_sk, to_sk, samples) -> np.ndarray:
+        """KeySwitchingKey::generate_ksk key_switching.rs:20-60 with the context's ks_decomposer:
+        samples [from_dim*l_ks][to_dim+1] pre-filled."""
+        f, t = _np(from_sk).reshape(-1), _np(to_sk).reshape(-1)
+        out = _np(samples).copy()
+        assert out.shape == (f.size * self.params.ks_decomposer.levels, t.size + 1)
+        self._check(lib().tfhe_generate_ksk(self._h, _hp(f), C.c_size_t(f.size), _hp(t), C.c_size_t(t.size),
+                                            _hp(out)))
+        return out
+
+    def bootstrapping_key_gen(self, lwe_sk, glwe_sk, bsk_samples, ksk_samples, load: bool = True):
+        """bootstrapping_key_gen bootstrapping.rs:23-56 on pre-filled bsk / ksk buffers -> (bsk, ksk);
+        `load` installs the key in this context.  Torch device tensors are completed in place."""
+        p = self.params
+        lsk, gsk = _np(lwe_sk).reshape(p.n), _np(glwe_sk).reshape(p.k, p.N)
+        if _is_torch(bsk_samples):
+            assert tuple(bsk_samples.shape) == p.bsk_shape() and tuple(ksk_samples.shape) == p.ksk_shape()
+            self._check(lib().tfhe_bootstrapping_key_gen_device(self._h, _hp(lsk), _hp(gsk), _dp(bsk_samples),
+                                                                _dp(ksk_samples), C.c_int(int(load))))
+            return bsk_samples, ksk_samples
+        bsk, ksk = _np(bsk_samples).copy(), _np(ksk_samples).copy()
+        assert bsk.shape == p.bsk_shape() and ksk.shape == p.ksk_shape()
+        self._check(lib().tfhe_bootstrapping_key_gen(self._h, _hp(lsk), _hp(gsk), _hp(bsk), _hp(ksk),
+                                                     C.c_int(int(load))))
+        return bsk, ksk

@@ -54,6 +54,8 @@ struct tfhe_context {
   size_t ggsw_tmp_words = 0;
   u32* d_ggsw_raw = nullptr;
   size_t ggsw_raw_words = 0;
+  u32* d_key_tmp = nullptr;   // secret keys / messages of the encryption-side calls
+  size_t key_tmp_words = 0;
 
   bool timing = false;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // br start/stop, ks start/stop
@@ -354,7 +356,8 @@ void tfhe_context_destroy(tfhe_context* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   void* ptrs[] = {ctx->d_tw,     ctx->d_bsk,    ctx->d_ksk,    ctx->d_lwe_in, ctx->d_lwe_in2,
                   ctx->d_lwe_big, ctx->d_lwe_out, ctx->d_glwe_a, ctx->d_glwe_b, ctx->d_glwe_c,
-                  ctx->d_tv,     ctx->d_tv_gate, ctx->d_misc,   ctx->d_ggsw_tmp, ctx->d_ggsw_raw};
+                  ctx->d_tv,     ctx->d_tv_gate, ctx->d_misc,   ctx->d_ggsw_tmp, ctx->d_ggsw_raw,
+                  ctx->d_key_tmp};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& ev : ctx->ev)
@@ -761,6 +764,261 @@ int tfhe_lwe_linear_batch(tfhe_context* ctx, uint32_t c0, const uint32_t* ct0, u
   HIP_TRY(ctx, hipMemcpyAsync(out, dout, words * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return TFHE_OK;
+}
+
+// ---------------------------------------------------------------------------------- encryption side
+// keygen / encrypt / decrypt with the caller's randomness already in the buffers (tfhe_hip.h)
+namespace {
+
+int check_binary(tfhe_context* ctx, const u32* sk, size_t words, const char* what) {
+  for (size_t i = 0; i < words; ++i)
+    if (sk[i] > 1u)
+      return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, std::string(what) + " must be binary (sample_binary)");
+  return TFHE_OK;
+}
+
+int ensure_key_tmp(tfhe_context* ctx, size_t words) {
+  if (words <= ctx->key_tmp_words) return TFHE_OK;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return ensure(ctx, &ctx->d_key_tmp, &ctx->key_tmp_words, words);
+}
+
+int to_key_tmp(tfhe_context* ctx, const u32* host, size_t words, size_t at) {
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_key_tmp + at, host, words * sizeof(u32), hipMemcpyHostToDevice,
+                              ctx->stream));
+  return TFHE_OK;
+}
+
+// rows of GLWE ciphertexts [rows][k+1][N] on the device; sk already at d_key_tmp[0 .. kN)
+int glwe_rows_add_mask_dot_key(tfhe_context* ctx, u32* d_rows, size_t rows) {
+  const u32 k = ctx->params.glwe_dimension;
+  HIP_TRY(ctx, launch::glwe_body(ctx->stream, ctx->field, ctx->pbs.log_n, ctx->d_tw, k, d_rows, rows,
+                                 ctx->d_key_tmp, d_rows + (size_t)k * ctx->N,
+                                 (size_t)(k + 1) * ctx->N, false));
+  return TFHE_OK;
+}
+
+// generate_ksk (key_switching.rs:20-60) on device rows; both keys are host pointers
+int ksk_gen_device(tfhe_context* ctx, const u32* from_sk, size_t from_dim, const u32* to_sk,
+                   size_t to_dim, u32* d_ksk) {
+  int st;
+  const u32 levels = ctx->ks.levels, log_base = ctx->ks.log_base;
+  const u32 l_full = 32 / log_base;
+  const size_t rows = from_dim * levels;
+  // row s*levels + level carries s_bit * 2^{log_base*(l - (level+1))} in its b slot (:36-45)
+  std::vector<u32> factor(rows);
+  for (size_t s = 0; s < from_dim; ++s)
+    for (u32 level = 0; level < levels; ++level)
+      factor[s * levels + level] = (1u << (log_base * (l_full - (level + 1)))) * from_sk[s];
+  if ((st = ensure_key_tmp(ctx, to_dim + rows))) return st;
+  if ((st = to_key_tmp(ctx, to_sk, to_dim, 0))) return st;
+  if ((st = to_key_tmp(ctx, factor.data(), rows, to_dim))) return st;
+  HIP_TRY(ctx, launch::lwe_body(ctx->stream, d_ksk, rows, (u32)to_dim, ctx->d_key_tmp,
+                                ctx->d_key_tmp + to_dim, d_ksk + to_dim, to_dim + 1, false));
+  // `factor` is pageable host memory: the async copy has staged it before returning
+  return TFHE_OK;
+}
+
+}  // namespace
+
+int tfhe_glwe_encrypt_zero_batch_device(tfhe_context* ctx, const uint32_t* glwe_sk, uint32_t* glwe,
+                                        size_t count) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  if (!glwe_sk || !glwe || count == 0) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer / empty batch");
+  const size_t kn = (size_t)ctx->params.glwe_dimension * ctx->N;
+  if ((st = check_binary(ctx, glwe_sk, kn, "glwe secret key"))) return st;
+  if ((st = ensure_key_tmp(ctx, kn))) return st;
+  if ((st = to_key_tmp(ctx, glwe_sk, kn, 0))) return st;
+  return glwe_rows_add_mask_dot_key(ctx, glwe, count);
+}
+
+int tfhe_glwe_encrypt_zero_batch(tfhe_context* ctx, const uint32_t* glwe_sk, uint32_t* glwe, size_t count) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  if (!glwe_sk || !glwe || count == 0) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer / empty batch");
+  const size_t words = count * (size_t)(ctx->params.glwe_dimension + 1) * ctx->N;
+  if ((st = ensure_misc(ctx, words * sizeof(u32)))) return st;
+  u32* d = reinterpret_cast<u32*>(ctx->d_misc);
+  HIP_TRY(ctx, hipMemcpyAsync(d, glwe, words * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+  if ((st = tfhe_glwe_encrypt_zero_batch_device(ctx, glwe_sk, d, count))) return st;
+  HIP_TRY(ctx, hipMemcpyAsync(glwe, d, words * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return TFHE_OK;
+}
+
+int tfhe_glwe_decrypt_batch(tfhe_context* ctx, const uint32_t* glwe_sk, const uint32_t* glwe, size_t count,
+                            uint32_t* plaintext_out) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  if (!glwe_sk || !glwe || !plaintext_out || count == 0) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer / empty batch");
+  const u32 k = ctx->params.glwe_dimension;
+  const size_t kn = (size_t)k * ctx->N;
+  const size_t words = count * (size_t)(k + 1) * ctx->N;
+  if ((st = check_binary(ctx, glwe_sk, kn, "glwe secret key"))) return st;
+  if ((st = ensure_key_tmp(ctx, kn))) return st;
+  if ((st = ensure_misc(ctx, (words + count * ctx->N) * sizeof(u32)))) return st;
+  u32* d = reinterpret_cast<u32*>(ctx->d_misc);
+  u32* d_out = d + words;
+  if ((st = to_key_tmp(ctx, glwe_sk, kn, 0))) return st;
+  HIP_TRY(ctx, hipMemcpyAsync(d, glwe, words * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, launch::glwe_body(ctx->stream, ctx->field, ctx->pbs.log_n, ctx->d_tw, k, d, count,
+                                 ctx->d_key_tmp, d_out, ctx->N, true));
+  HIP_TRY(ctx, hipMemcpyAsync(plaintext_out, d_out, count * ctx->N * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return TFHE_OK;
+}
+
+int tfhe_ggsw_encrypt_batch_device(tfhe_context* ctx, const uint32_t* glwe_sk, const uint32_t* messages,
+                                   uint32_t* ggsw, size_t count) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  if (!glwe_sk || !messages || !ggsw || count == 0) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer / empty batch");
+  const u32 k = ctx->params.glwe_dimension;
+  const size_t kn = (size_t)k * ctx->N;
+  if ((st = check_binary(ctx, glwe_sk, kn, "glwe secret key"))) return st;
+  if ((st = ensure_key_tmp(ctx, kn + count))) return st;
+  if ((st = to_key_tmp(ctx, glwe_sk, kn, 0))) return st;
+  if ((st = to_key_tmp(ctx, messages, count, kn))) return st;
+  if ((st = glwe_rows_add_mask_dot_key(ctx, ggsw, count * ctx->R))) return st;
+  HIP_TRY(ctx, launch::ggsw_add_gadget(ctx->stream, ggsw, count, k, ctx->pbs.log_n, ctx->pbs.levels,
+                                       ctx->pbs.log_base, ctx->d_key_tmp + kn));
+  return TFHE_OK;
+}
+
+int tfhe_ggsw_encrypt_batch(tfhe_context* ctx, const uint32_t* glwe_sk, const uint32_t* messages,
+                            uint32_t* ggsw, size_t count) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  if (!glwe_sk || !messages || !ggsw || count == 0) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer / empty batch");
+  const size_t words = count * ggsw_words(ctx);
+  if ((st = ensure_misc(ctx, words * sizeof(u32)))) return st;
+  u32* d = reinterpret_cast<u32*>(ctx->d_misc);
+  HIP_TRY(ctx, hipMemcpyAsync(d, ggsw, words * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+  if ((st = tfhe_ggsw_encrypt_batch_device(ctx, glwe_sk, messages, d, count))) return st;
+  HIP_TRY(ctx, hipMemcpyAsync(ggsw, d, words * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return TFHE_OK;
+}
+
+int tfhe_lwe_encrypt_batch_device(tfhe_context* ctx, const uint32_t* lwe_sk, size_t dimension,
+                                  const uint32_t* plaintexts, uint32_t* lwe, size_t batch) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  if (!lwe_sk || !lwe || batch == 0 || dimension == 0 || dimension >= (1u << 31))
+    return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer / empty batch / bad dimension");
+  if ((st = check_binary(ctx, lwe_sk, dimension, "lwe secret key"))) return st;
+  if ((st = ensure_key_tmp(ctx, dimension))) return st;
+  if ((st = to_key_tmp(ctx, lwe_sk, dimension, 0))) return st;
+  HIP_TRY(ctx, launch::lwe_body(ctx->stream, lwe, batch, (u32)dimension, ctx->d_key_tmp, plaintexts,
+                                lwe + dimension, dimension + 1, false));
+  return TFHE_OK;
+}
+
+int tfhe_lwe_encrypt_batch(tfhe_context* ctx, const uint32_t* lwe_sk, size_t dimension,
+                           const uint32_t* plaintexts, uint32_t* lwe, size_t batch) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  if (!lwe_sk || !lwe || batch == 0 || dimension == 0) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer / empty batch");
+  const size_t words = batch * (dimension + 1);
+  if ((st = ensure_misc(ctx, (words + batch) * sizeof(u32)))) return st;
+  u32* d = reinterpret_cast<u32*>(ctx->d_misc);
+  u32* d_pt = d + words;
+  HIP_TRY(ctx, hipMemcpyAsync(d, lwe, words * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+  if (plaintexts)
+    HIP_TRY(ctx, hipMemcpyAsync(d_pt, plaintexts, batch * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+  if ((st = tfhe_lwe_encrypt_batch_device(ctx, lwe_sk, dimension, plaintexts ? d_pt : nullptr, d, batch))) return st;
+  HIP_TRY(ctx, hipMemcpyAsync(lwe, d, words * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return TFHE_OK;
+}
+
+int tfhe_lwe_decrypt_batch_device(tfhe_context* ctx, const uint32_t* lwe_sk, size_t dimension,
+                                  const uint32_t* lwe, size_t batch, uint32_t* plaintext_out) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  if (!lwe_sk || !lwe || !plaintext_out || batch == 0 || dimension == 0 || dimension >= (1u << 31))
+    return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer / empty batch / bad dimension");
+  if ((st = check_binary(ctx, lwe_sk, dimension, "lwe secret key"))) return st;
+  if ((st = ensure_key_tmp(ctx, dimension))) return st;
+  if ((st = to_key_tmp(ctx, lwe_sk, dimension, 0))) return st;
+  HIP_TRY(ctx, launch::lwe_body(ctx->stream, lwe, batch, (u32)dimension, ctx->d_key_tmp, nullptr,
+                                plaintext_out, 1, true));
+  return TFHE_OK;
+}
+
+int tfhe_lwe_decrypt_batch(tfhe_context* ctx, const uint32_t* lwe_sk, size_t dimension, const uint32_t* lwe,
+                           size_t batch, uint32_t* plaintext_out) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  if (!lwe_sk || !lwe || !plaintext_out || batch == 0 || dimension == 0) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer / empty batch");
+  const size_t words = batch * (dimension + 1);
+  if ((st = ensure_misc(ctx, (words + batch) * sizeof(u32)))) return st;
+  u32* d = reinterpret_cast<u32*>(ctx->d_misc);
+  u32* d_out = d + words;
+  HIP_TRY(ctx, hipMemcpyAsync(d, lwe, words * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+  if ((st = tfhe_lwe_decrypt_batch_device(ctx, lwe_sk, dimension, d, batch, d_out))) return st;
+  HIP_TRY(ctx, hipMemcpyAsync(plaintext_out, d_out, batch * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return TFHE_OK;
+}
+
+int tfhe_generate_ksk(tfhe_context* ctx, const uint32_t* from_sk, size_t from_dimension,
+                      const uint32_t* to_sk, size_t to_dimension, uint32_t* ksk) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  if (!from_sk || !to_sk || !ksk || from_dimension == 0 || to_dimension == 0 || to_dimension >= (1u << 31))
+    return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer / bad dimension");
+  if ((st = check_binary(ctx, from_sk, from_dimension, "from secret key"))) return st;
+  if ((st = check_binary(ctx, to_sk, to_dimension, "to secret key"))) return st;
+  const size_t words = from_dimension * ctx->ks.levels * (to_dimension + 1);
+  if ((st = ensure_misc(ctx, words * sizeof(u32)))) return st;
+  u32* d = reinterpret_cast<u32*>(ctx->d_misc);
+  HIP_TRY(ctx, hipMemcpyAsync(d, ksk, words * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+  if ((st = ksk_gen_device(ctx, from_sk, from_dimension, to_sk, to_dimension, d))) return st;
+  HIP_TRY(ctx, hipMemcpyAsync(ksk, d, words * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return TFHE_OK;
+}
+
+int tfhe_bootstrapping_key_gen_device(tfhe_context* ctx, const uint32_t* lwe_sk, const uint32_t* glwe_sk,
+                                      uint32_t* bsk, uint32_t* ksk, int load) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  if (!lwe_sk || !glwe_sk || !bsk || !ksk) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer");
+  const size_t n = ctx->params.lwe_dimension;
+  if ((st = check_binary(ctx, lwe_sk, n, "lwe secret key"))) return st;
+  // encrypt each bit of the lwe secret key (bootstrapping.rs:32-38)
+  if ((st = tfhe_ggsw_encrypt_batch_device(ctx, glwe_sk, lwe_sk, bsk, n))) return st;
+  // key switching key from the flattened GLWE key to the LWE key (:41-51, lwe.rs:62-73)
+  if ((st = ksk_gen_device(ctx, glwe_sk, ctx->big_n, lwe_sk, n, ksk))) return st;
+  if (load) return load_key_common(ctx, bsk, ksk, true);
+  return TFHE_OK;
+}
+
+int tfhe_bootstrapping_key_gen(tfhe_context* ctx, const uint32_t* lwe_sk, const uint32_t* glwe_sk,
+                               uint32_t* bsk, uint32_t* ksk, int load) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  if (!lwe_sk || !glwe_sk || !bsk || !ksk) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer");
+  const size_t bsk_words = (size_t)ctx->params.lwe_dimension * ggsw_words(ctx);
+  const size_t ksk_words = (size_t)ctx->big_n * ctx->ks.levels * ((size_t)ctx->params.lwe_dimension + 1);
+  u32 *d_bsk = nullptr, *d_ksk = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_bsk), bsk_words * sizeof(u32));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_ksk), ksk_words * sizeof(u32));
+  if (e == hipSuccess) e = hipMemcpy(d_bsk, bsk, bsk_words * sizeof(u32), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_ksk, ksk, ksk_words * sizeof(u32), hipMemcpyHostToDevice);
+  st = (e == hipSuccess) ? tfhe_bootstrapping_key_gen_device(ctx, lwe_sk, glwe_sk, d_bsk, d_ksk, load)
+                         : hip_fail(ctx, e, "key buffers");
+  if (st == TFHE_OK) {
+    e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(bsk, d_bsk, bsk_words * sizeof(u32), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(ksk, d_ksk, ksk_words * sizeof(u32), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) st = hip_fail(ctx, e, "key download");
+  }
+  if (d_bsk) (void)hipFree(d_bsk);
+  if (d_ksk) (void)hipFree(d_ksk);
+  return st;
 }
 
 // ---------------------------------------------------------------------------------- test vectors / gates

@@ -372,6 +372,92 @@ __global__ void lwe_linear_kernel(u32 c0, const u32* ct0, u32 c1, const u32* ct1
     out[i] = c0 * ct0[i] + (ct1 ? c1 * ct1[i] : 0u);
 }
 
+// ------------------------------------------------------------------------------ encryption side
+// dst[row][j] = body_in[row][j] +/- sum_i masks[row][i] (*) sk[i]: one GLWE row [k+1][N] per group
+// of G waves, 4/G rows per workgroup.  Encrypt (glwe.rs:190-209): body_in holds the caller's error
+// samples, dst = the body itself.  Decrypt (glwe.rs:245-265): dst = plaintext rows, negate = 1.
+template <class F, int LOGN>
+__global__ void __launch_bounds__(256) glwe_body_kernel(const typename F::elem* __restrict__ tw, u32 k,
+                                                       const u32* rows, size_t row_count,
+                                                       const u32* __restrict__ sk, u32* dst,
+                                                       size_t dst_stride, u32 negate,
+                                                       typename F::elem n_inv) {
+  typedef typename F::elem elem;
+  constexpr int N = 1 << LOGN;
+  constexpr int G = GroupOf<LOGN>::value;
+  elem* twl = reinterpret_cast<elem*>(g_smem);
+  for (int i = threadIdx.x; i < ntt_twiddle_words(N); i += blockDim.x) twl[i] = tw[i];
+  __syncthreads();
+  const int group = (int)(threadIdx.x / (64u * G));
+  const int groups = (int)(blockDim.x / (64u * G));
+  // G > 1: the transforms contain workgroup barriers, so a group past the end redoes the last row
+  // (same values to the same addresses) instead of leaving -- as in bsk_prepare_kernel
+  size_t row = (size_t)blockIdx.x * groups + group;
+  bool live = true;
+  if (row >= row_count) {
+    if (G == 1) return;
+    row = row_count - 1;
+    live = false;
+  }
+  DeviceWave<elem, G> w;
+  w.group_ = 0;
+  w.group_stride_ = 0;
+  w.team_base_ = nullptr;
+  w.tw_ = twl;
+  w.scratch_ = reinterpret_cast<elem*>(g_smem + (size_t)ntt_twiddle_words(N) * 8 + (size_t)group * N * 8);
+  w.acc_ = nullptr;
+  const u32* masks = rows + row * (size_t)(k + 1) * N;
+  const u32* body = masks + (size_t)k * N;
+  u32* d = dst + row * dst_stride;
+  auto out = [&](int j, u32 dot) {
+    // body[j] is read before d[j] is written by the same lane, so d may alias body
+    const u32 b = body[j];
+    if (live) d[j] = negate ? b - dot : b + dot;
+  };
+  glwe_mask_dot_key<F, LOGN, G>(w, k, masks, sk, n_inv, out);
+}
+
+// dst[row] = lwe[row][n] +/- <lwe[row][0..n), sk> (+ plaintext[row]): one LWE row per wavefront.
+// Encrypt (lwe.rs:117-160, and the rows of generate_ksk key_switching.rs:41-45): the b slot holds
+// the caller's error sample, dst = the b slot.  Decrypt (lwe.rs:162-173): negate = 1.
+__global__ void __launch_bounds__(256) lwe_body_kernel(const u32* rows, size_t row_count, u32 n,
+                                                      const u32* __restrict__ sk,
+                                                      const u32* __restrict__ plaintext, u32* dst,
+                                                      size_t dst_stride, u32 negate) {
+  const size_t row = (size_t)blockIdx.x * (blockDim.x / 64u) + threadIdx.x / 64u;
+  if (row >= row_count) return;
+  const u32 lane = threadIdx.x & 63u;
+  const u32* ct = rows + row * ((size_t)n + 1);
+  u32 dot = 0;
+  for (u32 j = lane; j < n; j += 64u) dot += ct[j] * sk[j];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
+  if (lane == 0) {
+    const u32 b = ct[n];
+    u32 v = negate ? b - dot : b + dot;
+    if (plaintext) v += plaintext[row];
+    dst[row * dst_stride] = v;
+  }
+}
+
+// ggsw.rs:96-103: row = poly_index*levels + level of GGSW g gets
+// messages[g] * 2^{log_base*(floor(32/log_base) - (level+1))} added to coefficient 0 of polynomial
+// poly_index (after the zero encryption was formed from the unmodified masks)
+__global__ void ggsw_add_gadget_kernel(u32* ggsw, size_t ggsw_count, u32 k, u32 log_n, u32 levels,
+                                       u32 log_base, const u32* __restrict__ messages) {
+  const size_t rows = (size_t)(k + 1) * levels;
+  const size_t total = ggsw_count * rows;
+  const u32 l_full = 32 / log_base;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const size_t g = i / rows;
+    const u32 row = (u32)(i % rows);
+    const u32 poly_index = row / levels, level = row % levels;
+    const u32 factor = messages[g] * (1u << (log_base * (l_full - (level + 1))));
+    ggsw[(((g * rows + row) * (k + 1)) + poly_index) << log_n] += factor;
+  }
+}
+
 inline int grid_for(size_t work, int block) {
   size_t g = (work + block - 1) / block;
   if (g > 2048) g = 2048;  // 256 CUs x 8: grid-stride the rest
@@ -438,6 +524,23 @@ hipError_t launch_bsk_prepare(hipStream_t s, const void* tw_v, const u32* polys,
   const unsigned grid = (unsigned)((poly_count + groups - 1) / groups);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, tw, polys, poly_count, spectra,
                      F::n_inv(LOGN));
+  return hipGetLastError();
+}
+
+template <class F, int LOGN>
+hipError_t launch_glwe_body(hipStream_t s, const void* tw_v, u32 k, const u32* rows, size_t row_count,
+                            const u32* sk, u32* dst, size_t dst_stride, u32 negate) {
+  constexpr int N = 1 << LOGN;
+  constexpr int G = GroupOf<LOGN>::value;
+  constexpr int groups = 4 / G;  // rows per 256-thread workgroup
+  const size_t lds = (size_t)ntt_twiddle_words(N) * 8 + (size_t)N * 8 * groups;
+  auto tw = static_cast<const typename F::elem*>(tw_v);
+  auto kern = glwe_body_kernel<F, LOGN>;
+  hipError_t e = allow_lds(kern, lds);
+  if (e != hipSuccess) return e;
+  const unsigned grid = (unsigned)((row_count + groups - 1) / groups);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, tw, k, rows, row_count, sk, dst, dst_stride,
+                     negate, F::n_inv(LOGN));
   return hipGetLastError();
 }
 
@@ -592,6 +695,29 @@ hipError_t lwe_linear(hipStream_t s, u32 c0, const u32* ct0, u32 c1, const u32* 
                       u32* out) {
   hipLaunchKernelGGL(lwe_linear_kernel, dim3(grid_for(words, 256)), dim3(256), 0, s, c0, ct0, c1, ct1,
                      words, out);
+  return hipGetLastError();
+}
+
+hipError_t glwe_body(hipStream_t s, int field, u32 log_n, const void* tw, u32 k, const u32* rows,
+                     size_t row_count, const u32* sk, u32* dst, size_t dst_stride, bool negate) {
+  if (row_count == 0) return hipSuccess;
+  TFHE_DISPATCH_FIELD(field, TFHE_DISPATCH_LOGN(log_n, (launch_glwe_body<FF, LL>(s, tw, k, rows, row_count, sk, dst, dst_stride, negate ? 1u : 0u))));
+}
+
+hipError_t lwe_body(hipStream_t s, const u32* rows, size_t row_count, u32 n, const u32* sk,
+                    const u32* plaintext, u32* dst, size_t dst_stride, bool negate) {
+  if (row_count == 0) return hipSuccess;
+  const unsigned grid = (unsigned)((row_count + 3) / 4);
+  hipLaunchKernelGGL(lwe_body_kernel, dim3(grid), dim3(256), 0, s, rows, row_count, n, sk, plaintext,
+                     dst, dst_stride, negate ? 1u : 0u);
+  return hipGetLastError();
+}
+
+hipError_t ggsw_add_gadget(hipStream_t s, u32* ggsw, size_t ggsw_count, u32 k, u32 log_n, u32 levels,
+                           u32 log_base, const u32* messages) {
+  const size_t total = ggsw_count * (size_t)(k + 1) * levels;
+  hipLaunchKernelGGL(ggsw_add_gadget_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, ggsw,
+                     ggsw_count, k, log_n, levels, log_base, messages);
   return hipGetLastError();
 }
 

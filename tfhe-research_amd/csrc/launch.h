@@ -55,5 +55,17 @@ hipError_t sample_extract(hipStream_t s, u32 log_n, u32 k, const u32* glwe, size
 hipError_t lwe_linear(hipStream_t s, u32 c0, const u32* ct0, u32 c1, const u32* ct1, size_t words,
                       u32* out);
 
+// ---- encryption side (keygen / encrypt / decrypt with caller-supplied randomness)
+// dst[row][j] = body(rows[row])[j] +/- sum_i masks(rows[row])[i] (*) sk[i]; rows [row_count][k+1][N],
+// sk [k][N] binary, dst rows of dst_stride words (may alias the bodies)
+hipError_t glwe_body(hipStream_t s, int field, u32 log_n, const void* tw, u32 k, const u32* rows,
+                     size_t row_count, const u32* sk, u32* dst, size_t dst_stride, bool negate);
+// dst[row*dst_stride] = rows[row][n] +/- <rows[row][0..n), sk> (+ plaintext[row] if non-null)
+hipError_t lwe_body(hipStream_t s, const u32* rows, size_t row_count, u32 n, const u32* sk,
+                    const u32* plaintext, u32* dst, size_t dst_stride, bool negate);
+// ggsw.rs:96-103 for ggsw_count matrices [(k+1)*levels][k+1][N]
+hipError_t ggsw_add_gadget(hipStream_t s, u32* ggsw, size_t ggsw_count, u32 k, u32 log_n, u32 levels,
+                           u32 log_base, const u32* messages);
+
 }  // namespace launch
 }  // namespace tfhe

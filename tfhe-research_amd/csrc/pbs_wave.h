@@ -308,4 +308,62 @@ TFHE_HD void bsk_prepare_wave(const Ctx& c, const u32* poly, typename F::elem* s
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// sum_{i<k} masks[i] (*) sk[i], negacyclic mod 2^32, by one group of G waves: the a*s term of
+// encrypt_glwe_zero (glwe.rs:197, poly_dot_product utils.rs:163-173) and of
+// decrypt_glwe_ciphertext (glwe.rs:252).  The secret polynomials are BINARY (sample_binary): they
+// play the digit role (small operand, F::from_digit), the uniform mask words the key role
+// (F::from_key_word splits them into F::kParts limbs), so the field bound is the external
+// product's with k rows of digits of magnitude 1.  out(j, value mod 2^32) once per coefficient.
+// ---------------------------------------------------------------------------------------------
+template <class F, int LOGN, int G, class Ctx, class Out>
+TFHE_HD void glwe_mask_dot_key(const Ctx& c, u32 k, const u32* masks /* [k][N] */,
+                               const u32* sk /* [k][N] */, typename F::elem n_inv, Out out) {
+  typedef typename F::elem elem;
+  constexpr int E = NttShape<LOGN, G>::kE;
+  constexpr int T = NttShape<LOGN, G>::kThreads;
+  constexpr int N = 1 << LOGN;
+  constexpr int PARTS = F::kParts;
+  const int lane = c.tid();
+
+  elem accum[PARTS][E];
+#pragma unroll
+  for (int q = 0; q < PARTS; ++q)
+#pragma unroll
+    for (int r = 0; r < E; ++r) accum[q][r] = F::zero();
+
+#pragma unroll 1
+  for (u32 i = 0; i < k; ++i) {
+    elem s[E];
+#pragma unroll
+    for (int r = 0; r < E; ++r) s[r] = F::from_digit(sk[(size_t)i * N + r * T + lane]);
+    ntt_forward<F, LOGN, G, true>(c, s);
+#pragma unroll
+    for (int r = 0; r < E; ++r) s[r] = F::mul(s[r], n_inv);
+    static_for<0, PARTS>([&](auto part_c) {
+      constexpr int q = decltype(part_c)::value;
+      elem x[E];
+#pragma unroll
+      for (int r = 0; r < E; ++r) x[r] = F::from_key_word(masks[(size_t)i * N + r * T + lane], q);
+      ntt_forward<F, LOGN, G>(c, x);
+#pragma unroll
+      for (int r = 0; r < E; ++r) accum[q][r] = F::add(accum[q][r], F::mul(x[r], s[r]));
+    });
+  }
+
+  static_for<0, PARTS>([&](auto part_c) {
+    constexpr int q = decltype(part_c)::value;
+#pragma unroll
+    for (int r = 0; r < E; ++r) accum[q][r] = F::before_inverse(accum[q][r]);
+    ntt_inverse<F, LOGN, G>(c, accum[q]);
+  });
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    elem parts[PARTS];
+#pragma unroll
+    for (int q = 0; q < PARTS; ++q) parts[q] = accum[q][r];
+    out(r * T + lane, F::finish(parts));
+  }
+}
+
 }  // namespace tfhe
