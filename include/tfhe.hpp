@@ -269,6 +269,28 @@ inline LweCiphertext xor_(Engine& e, const LweCiphertext& ct0, const LweCipherte
   const uint32_t t[4] = {0, 1, 1, 0};
   return gate(e, t, ct0, ct1);
 }
+// Gates beyond the reference's two, by notes/Boolean Gates.md:2-11.
+// NOT needs no bootstrap: (-a, enc(1) - b)
+inline LweCiphertext not_(Engine& e, const LweCiphertext& ct) {
+  LweCiphertext out{std::vector<uint32_t>(ct.data.size())};
+  e.check(tfhe_lwe_not_batch(e.raw(), ct.data.data(), 1, out.data.data()));
+  return out;
+}
+// gate of m inputs: one PBS of sum_i 2^i * cts[i] (cts[0] = rightmost input), truth has 2^m entries;
+// needs params.log_p >= m
+inline LweCiphertext lut_gate(Engine& e, const std::vector<uint32_t>& truth, const std::vector<const LweCiphertext*>& cts) {
+  if (cts.empty() || truth.size() != (size_t(1) << cts.size())) throw TfheError(TFHE_ERR_INVALID_ARGUMENT, "truth table size");
+  std::vector<const uint32_t*> ptrs;
+  for (const LweCiphertext* c : cts) ptrs.push_back(c->data.data());
+  LweCiphertext out{std::vector<uint32_t>(cts[0]->data.size())};
+  e.check(tfhe_lut_gate_batch(e.raw(), truth.data(), (uint32_t)cts.size(), ptrs.data(), 1, out.data.data()));
+  return out;
+}
+// sel ? a : b with two bootstraps at any log_p >= 2: AND(sel, a) + AND(NOT sel, b)
+inline LweCiphertext mux(Engine& e, const LweCiphertext& sel, const LweCiphertext& a, const LweCiphertext& b) {
+  const uint32_t t_and[4] = {0, 0, 0, 1}, t_andnot[4] = {0, 1, 0, 0};  // truth[(lhs << 1) | rhs], lhs = sel
+  return gate(e, t_and, a, sel) + gate(e, t_andnot, b, sel);
+}
 
 // ------------------------------------------------------------------------------------------------
 // Encryption side.  The reference threads `rng: &mut R` through keygen and

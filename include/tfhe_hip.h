@@ -197,6 +197,18 @@ int tfhe_gate_batch(tfhe_context *ctx, const uint32_t truth[4], const uint32_t *
                     const uint32_t *ct1, size_t batch, uint32_t *lwe_out);
 int tfhe_gate_batch_device(tfhe_context *ctx, const uint32_t truth[4], const uint32_t *ct0,
                            const uint32_t *ct1, size_t batch, uint32_t *lwe_out);
+/* Gates of m inputs by the same recipe (notes/Boolean Gates.md:2-11): one PBS of
+ * c_in = sum_i 2^i * cts[i] (cts[0] = rightmost / least significant input) with the test vector of
+ * lut[x] = truth[x mod 2^m]; truth has 2^m entries < 2^log_p; 1 <= m <= min(log_p, 8) -- three-input
+ * gates need a context with log_p >= 3.  cts is an array of m pointers to [batch][n+1]. */
+int tfhe_lut_gate_batch(tfhe_context *ctx, const uint32_t *truth, uint32_t inputs,
+                        const uint32_t *const *cts, size_t batch, uint32_t *lwe_out);
+int tfhe_lut_gate_batch_device(tfhe_context *ctx, const uint32_t *truth, uint32_t inputs,
+                               const uint32_t *const *cts, size_t batch, uint32_t *lwe_out);
+/* NOT without a bootstrap: (-a, enc(1) - b) with enc(1) = 1 << (32 - log_p - padding_bits) */
+int tfhe_lwe_not_batch(tfhe_context *ctx, const uint32_t *ct, size_t batch, uint32_t *lwe_out);
+int tfhe_lwe_not_batch_device(tfhe_context *ctx, const uint32_t *ct, size_t batch,
+                              uint32_t *lwe_out);
 
 /* ---- encryption side: keygen / encrypt / decrypt --------------------------------
  * The reference draws its randomness from the caller's `rng: &mut R` (uniform masks with

@@ -93,6 +93,12 @@ int main() {
     LweCiphertext ct_in = ct1 * 2u + ct0;
     auto tv = construct_test_vector_boolean(tfhe_params, [](uint32_t l, uint32_t r) { return l & r; });
     EXPECT(bootstrap(engine, ct_in, tv).data == and_(engine, ct0, ct1).data, "and == bootstrap(2*ct1+ct0)");
+    EXPECT(decrypt(not_(engine, ct0)) == (1 - rhs), "not");
+    for (uint32_t s = 0; s < 2; ++s) {
+      LweCiphertext sel = encrypt(s);
+      EXPECT(decrypt(mux(engine, sel, ct1, ct0)) == (s ? lhs : rhs), "mux");
+    }
+    EXPECT(lut_gate(engine, {0, 1, 1, 0}, {&ct0, &ct1}).data == xor_(engine, ct0, ct1).data, "lut_gate m=2 == xor");
   }
   // external_product / cmux / key_switch_lwe / sample_extract / decompose: bit-exact vs oracle
   {

@@ -434,8 +434,17 @@ class Context:
                                                        idx.ctypes.data_as(C.POINTER(C.c_int64)), _hp(res)))
         return res
 
-    def lwe_linear(self, c0: int, ct0, c1: int = 0, ct1=None) -> np.ndarray:
+    def lwe_linear(self, c0: int, ct0, c1: int = 0, ct1=None, out=None):
         """c0*ct0 + c1*ct1 (wrapping): LweCiphertext Add / Mul<u32>, lwe.rs:9-23."""
+        if _is_torch(ct0):
+            import torch
+            if out is None:
+                out = torch.empty_like(ct0)
+            width = ct0.shape[-1]
+            self._check(lib().tfhe_lwe_linear_batch_device(
+                self._h, C.c_uint32(c0 & 0xFFFFFFFF), _dp(ct0), C.c_uint32(c1 & 0xFFFFFFFF),
+                _dp(ct1) if ct1 is not None else None, C.c_size_t(ct0.numel() // width), C.c_size_t(width), _dp(out)))
+            return out
         a = _np(ct0)
         rows = a.reshape(-1, a.shape[-1])
         b = _np(ct1).reshape(rows.shape) if ct1 is not None else None
@@ -443,6 +452,47 @@ class Context:
         self._check(lib().tfhe_lwe_linear_batch(self._h, C.c_uint32(c0 & 0xFFFFFFFF), _hp(rows),
                                                 C.c_uint32(c1 & 0xFFFFFFFF), _hp(b) if b is not None else None,
                                                 C.c_size_t(rows.shape[0]), C.c_size_t(rows.shape[1]), _hp(res)))
+        return res.reshape(a.shape)
+
+    def lut_gate(self, truth, cts, out=None):
+        """Gate of m = len(cts) inputs (notes/Boolean Gates.md:2-11): one PBS of sum_i 2^i * cts[i]
+        (cts[0] = rightmost input) with lut[x] = truth[x mod 2^m]; needs log_p >= m."""
+        p = self.params
+        m = len(cts)
+        assert len(truth) == 1 << m
+        arr = (C.c_uint32 * (1 << m))(*[int(v) for v in truth])
+        ptrs = (_u32p * m)()
+        if _is_torch(cts[0]):
+            import torch
+            batch = cts[0].shape[0]
+            for i, t in enumerate(cts):
+                assert tuple(t.shape) == (batch, p.n + 1)
+                ptrs[i] = _dp(t)
+            if out is None:
+                out = torch.empty_like(cts[0])
+            self._check(lib().tfhe_lut_gate_batch_device(self._h, arr, C.c_uint32(m), ptrs, C.c_size_t(batch), _dp(out)))
+            return out
+        host = [_np(t).reshape(-1, p.n + 1) for t in cts]
+        for i, t in enumerate(host):
+            assert t.shape == host[0].shape
+            ptrs[i] = _hp(t)
+        res = np.zeros_like(host[0])
+        self._check(lib().tfhe_lut_gate_batch(self._h, arr, C.c_uint32(m), ptrs, C.c_size_t(host[0].shape[0]), _hp(res)))
+        return res
+
+    def lwe_not(self, ct, out=None):
+        """NOT without a bootstrap: (-a, enc(1) - b)."""
+        p = self.params
+        if _is_torch(ct):
+            import torch
+            if out is None:
+                out = torch.empty_like(ct)
+            self._check(lib().tfhe_lwe_not_batch_device(self._h, _dp(ct), C.c_size_t(ct.numel() // (p.n + 1)), _dp(out)))
+            return out
+        a = _np(ct)
+        rows = a.reshape(-1, p.n + 1)
+        res = np.zeros_like(rows)
+        self._check(lib().tfhe_lwe_not_batch(self._h, _hp(rows), C.c_size_t(rows.shape[0]), _hp(res)))
         return res.reshape(a.shape)
 
     def gate(self, truth, ct0, ct1, out=None):

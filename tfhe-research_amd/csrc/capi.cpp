@@ -46,7 +46,7 @@ struct tfhe_context {
   u32* d_glwe_c = nullptr;
   u32* d_tv = nullptr;        // [batch][N] (or [1][N])
   u32* d_tv_gate = nullptr;   // [N] test vector of gate calls
-  u32 gate_truth[4] = {~0u, ~0u, ~0u, ~0u};  // truth table whose test vector d_tv_gate holds
+  std::vector<u32> gate_truth;  // truth table (2^inputs entries) whose test vector d_tv_gate holds
   // generic scratch for the small entry points
   void* d_misc = nullptr;
   size_t misc_bytes = 0;
@@ -1039,40 +1039,107 @@ int tfhe_construct_test_vector_boolean(const tfhe_params* params, const uint32_t
   return test_from_lut(params, lut.data(), pm, out);
 }
 
+// notes/Boolean Gates.md:2-11: a gate of m inputs is one PBS of c_in = sum_i 2^i * cts[i] with the
+// test vector of lut[x] = truth[x mod 2^m]; and()/or() (boolean.rs:9-53) are the m = 2 case.
+static int lut_gate_device(tfhe_context* ctx, const u32* truth, u32 inputs, const u32* const* cts,
+                           size_t batch, u32* lwe_out) {
+  int st;
+  if (!truth || !cts || !lwe_out || batch == 0) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer / empty batch");
+  if (inputs == 0 || inputs > ctx->params.log_p || inputs > 8)
+    return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "gate inputs must be 1..min(log_p, 8): the plaintext space holds log_p bits");
+  for (u32 i = 0; i < inputs; ++i)
+    if (!cts[i]) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null input ciphertext");
+  if (!ctx->have_key) return fail(ctx, TFHE_ERR_NO_KEY, "load the bootstrapping key first");
+  if ((st = reserve(ctx, batch))) return st;
+  const size_t words = batch * ((size_t)ctx->params.lwe_dimension + 1);
+  const u32 entries = 1u << inputs;
+  if (ctx->gate_truth.size() != entries || std::memcmp(ctx->gate_truth.data(), truth, entries * sizeof(u32)) != 0) {
+    // first use of this truth table: build its test vector on the host and upload it (this one
+    // call synchronises; repeated calls with the same gate do not)
+    const u32 pm = 1u << ctx->params.log_p;
+    std::vector<u32> lut(pm), tv(ctx->N);
+    for (u32 x = 0; x < pm; ++x) lut[x] = truth[x & (entries - 1)];  // test_vector.rs:16 for m = 2
+    if ((st = test_from_lut(&ctx->params, lut.data(), pm, tv.data())))
+      return fail(ctx, st, "truth table entries must be < 2^log_p (test_vector.rs:41)");
+    if ((st = check_tv_host(ctx, tv.data(), ctx->N))) return st;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_tv_gate, tv.data(), ctx->N * sizeof(u32), hipMemcpyHostToDevice));
+    ctx->gate_truth.assign(truth, truth + entries);
+  }
+  const u32* d_in = cts[0];
+  for (u32 i = 1; i < inputs; ++i) {  // 2*ct1 + ct0 (boolean.rs:18), then + 4*ct2, ...
+    HIP_TRY(ctx, launch::lwe_linear(ctx->stream, 1u, d_in, 1u << i, cts[i], words, ctx->d_lwe_in2));
+    d_in = ctx->d_lwe_in2;
+  }
+  return enqueue_bootstrap(ctx, d_in, batch, ctx->d_tv_gate, 1, ctx->d_lwe_big, lwe_out);
+}
+
 int tfhe_gate_batch_device(tfhe_context* ctx, const uint32_t truth[4], const uint32_t* ct0,
                            const uint32_t* ct1, size_t batch, uint32_t* lwe_out) {
   int st = check_ctx(ctx);
   if (st) return st;
-  if (!truth || !ct0 || !ct1 || !lwe_out || batch == 0) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer / empty batch");
-  if (!ctx->have_key) return fail(ctx, TFHE_ERR_NO_KEY, "load the bootstrapping key first");
-  if ((st = reserve(ctx, batch))) return st;
+  if (!ct0 || !ct1) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer / empty batch");
+  const u32* cts[2] = {ct0, ct1};
+  return lut_gate_device(ctx, truth, 2, cts, batch, lwe_out);
+}
+
+int tfhe_lut_gate_batch_device(tfhe_context* ctx, const uint32_t* truth, uint32_t inputs,
+                               const uint32_t* const* cts, size_t batch, uint32_t* lwe_out) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  return lut_gate_device(ctx, truth, inputs, cts, batch, lwe_out);
+}
+
+int tfhe_lut_gate_batch(tfhe_context* ctx, const uint32_t* truth, uint32_t inputs, const uint32_t* const* cts,
+                        size_t batch, uint32_t* lwe_out) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  if (!truth || !cts || !lwe_out || batch == 0 || inputs == 0 || inputs > 8)
+    return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer / empty batch / bad input count");
   const size_t words = batch * ((size_t)ctx->params.lwe_dimension + 1);
-  if (std::memcmp(ctx->gate_truth, truth, sizeof(ctx->gate_truth)) != 0) {
-    // first use of this truth table: build its test vector on the host and upload it (this one
-    // call synchronises; repeated calls with the same gate do not)
-    std::vector<u32> tv(ctx->N);
-    if ((st = tfhe_construct_test_vector_boolean(&ctx->params, truth, tv.data()))) return st;
-    if ((st = check_tv_host(ctx, tv.data(), ctx->N))) return st;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx, hipMemcpy(ctx->d_tv_gate, tv.data(), ctx->N * sizeof(u32), hipMemcpyHostToDevice));
-    std::memcpy(ctx->gate_truth, truth, sizeof(ctx->gate_truth));
+  if ((st = ensure_misc(ctx, (size_t)(inputs + 1) * words * sizeof(u32)))) return st;
+  u32* d = reinterpret_cast<u32*>(ctx->d_misc);
+  const u32* d_cts[8];
+  for (u32 i = 0; i < inputs; ++i) {
+    if (!cts[i]) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null input ciphertext");
+    HIP_TRY(ctx, hipMemcpyAsync(d + i * words, cts[i], words * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+    d_cts[i] = d + i * words;
   }
-  HIP_TRY(ctx, launch::lwe_linear(ctx->stream, 1u, ct0, 2u, ct1, words, ctx->d_lwe_in2));  // 2*ct1 + ct0
-  return enqueue_bootstrap(ctx, ctx->d_lwe_in2, batch, ctx->d_tv_gate, 1, ctx->d_lwe_big, lwe_out);
+  u32* d_out = d + (size_t)inputs * words;
+  if ((st = lut_gate_device(ctx, truth, inputs, d_cts, batch, d_out))) return st;
+  HIP_TRY(ctx, hipMemcpyAsync(lwe_out, d_out, words * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return TFHE_OK;
 }
 
 int tfhe_gate_batch(tfhe_context* ctx, const uint32_t truth[4], const uint32_t* ct0,
                     const uint32_t* ct1, size_t batch, uint32_t* lwe_out) {
+  const uint32_t* cts[2] = {ct0, ct1};
+  if (!ct0 || !ct1) return ctx ? fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer / empty batch") : TFHE_ERR_INVALID_ARGUMENT;
+  return tfhe_lut_gate_batch(ctx, truth, 2, cts, batch, lwe_out);
+}
+
+// NOT needs no bootstrap: an encryption of 1 - m is (-a, enc(1) - b), enc(1) = 1 << (32 - log_p - padding)
+int tfhe_lwe_not_batch_device(tfhe_context* ctx, const uint32_t* ct, size_t batch, uint32_t* lwe_out) {
   int st = check_ctx(ctx);
   if (st) return st;
-  if (!truth || !ct0 || !ct1 || !lwe_out || batch == 0) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer / empty batch");
-  if (!ctx->have_key) return fail(ctx, TFHE_ERR_NO_KEY, "load the bootstrapping key first");
-  if ((st = reserve(ctx, batch))) return st;
+  if (!ct || !lwe_out || batch == 0) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer / empty batch");
+  const size_t n1 = (size_t)ctx->params.lwe_dimension + 1;
+  const u32 one = 1u << (32 - ctx->params.log_p - ctx->params.padding_bits);
+  HIP_TRY(ctx, launch::lwe_linear(ctx->stream, 0xFFFFFFFFu, ct, 0u, nullptr, batch * n1, lwe_out, n1, one));
+  return TFHE_OK;
+}
+
+int tfhe_lwe_not_batch(tfhe_context* ctx, const uint32_t* ct, size_t batch, uint32_t* lwe_out) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  if (!ct || !lwe_out || batch == 0) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer / empty batch");
   const size_t words = batch * ((size_t)ctx->params.lwe_dimension + 1);
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_lwe_in, ct0, words * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_lwe_out, ct1, words * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
-  if ((st = tfhe_gate_batch_device(ctx, truth, ctx->d_lwe_in, ctx->d_lwe_out, batch, ctx->d_lwe_out))) return st;
-  HIP_TRY(ctx, hipMemcpyAsync(lwe_out, ctx->d_lwe_out, words * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+  if ((st = ensure_misc(ctx, 2 * words * sizeof(u32)))) return st;
+  u32* d = reinterpret_cast<u32*>(ctx->d_misc);
+  HIP_TRY(ctx, hipMemcpyAsync(d, ct, words * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+  if ((st = tfhe_lwe_not_batch_device(ctx, d, batch, d + words))) return st;
+  HIP_TRY(ctx, hipMemcpyAsync(lwe_out, d + words, words * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return TFHE_OK;
 }

@@ -365,11 +365,16 @@ __global__ void sample_extract_kernel(u32 log_n, u32 k, const u32* __restrict__ 
   }
 }
 
+// out = c0*ct0 + c1*ct1, plus b_add on the last word of every ciphertext of words_per_ct words
+// (words_per_ct == 0: no constant term)
 __global__ void lwe_linear_kernel(u32 c0, const u32* ct0, u32 c1, const u32* ct1, size_t words,
-                                  u32* out) {
+                                  size_t words_per_ct, u32 b_add, u32* out) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words;
-       i += (size_t)gridDim.x * blockDim.x)
-    out[i] = c0 * ct0[i] + (ct1 ? c1 * ct1[i] : 0u);
+       i += (size_t)gridDim.x * blockDim.x) {
+    u32 v = c0 * ct0[i] + (ct1 ? c1 * ct1[i] : 0u);
+    if (words_per_ct && (i % words_per_ct) == words_per_ct - 1) v += b_add;
+    out[i] = v;
+  }
 }
 
 // ------------------------------------------------------------------------------ encryption side
@@ -692,9 +697,9 @@ hipError_t sample_extract(hipStream_t s, u32 log_n, u32 k, const u32* glwe, size
 }
 
 hipError_t lwe_linear(hipStream_t s, u32 c0, const u32* ct0, u32 c1, const u32* ct1, size_t words,
-                      u32* out) {
+                      u32* out, size_t words_per_ct, u32 b_add) {
   hipLaunchKernelGGL(lwe_linear_kernel, dim3(grid_for(words, 256)), dim3(256), 0, s, c0, ct0, c1, ct1,
-                     words, out);
+                     words, words_per_ct, b_add, out);
   return hipGetLastError();
 }
 

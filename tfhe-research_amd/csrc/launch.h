@@ -51,9 +51,10 @@ hipError_t glwe_mul_monomial(hipStream_t s, u32 log_n, u32 polys_per_ct, const u
                              size_t batch, const i64* monomial_index, u32* out);
 hipError_t sample_extract(hipStream_t s, u32 log_n, u32 k, const u32* glwe, size_t batch,
                           u32 sample_index, u32* lwe_out);
-// out = c0*ct0 + c1*ct1 (ct1 may be null when c1 == 0); lwe.rs:9-23, boolean.rs:18
+// out = c0*ct0 + c1*ct1 (ct1 may be null when c1 == 0); lwe.rs:9-23, boolean.rs:18.  With
+// words_per_ct != 0, b_add is added to the b slot (last word) of every ciphertext.
 hipError_t lwe_linear(hipStream_t s, u32 c0, const u32* ct0, u32 c1, const u32* ct1, size_t words,
-                      u32* out);
+                      u32* out, size_t words_per_ct = 0, u32 b_add = 0);
 
 // ---- encryption side (keygen / encrypt / decrypt with caller-supplied randomness)
 // dst[row][j] = body(rows[row])[j] +/- sum_i masks(rows[row])[i] (*) sk[i]; rows [row_count][k+1][N],

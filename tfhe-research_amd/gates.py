@@ -2,15 +2,24 @@
 
 The reference offers two gates, and()/or() (boolean.rs:9-53), each of which is one programmable
 bootstrap of 2*ct1 + ct0 with a test vector built from a closure (test_vector.rs:5-20).  Any 2-input
-gate is the same bootstrap with another truth table, and a gate's output is a fresh encryption of a
-bit, so gates chain.  This module evaluates a whole graph of such gates with every ciphertext
-staying in HBM: wires live in one device tensor, each level's gates that share a truth table go to
-the GPU as ONE batched call of the C ABI's tfhe_gate_batch_device.
+gate is the same bootstrap with another truth table, a gate of m inputs is the bootstrap of
+sum_i 2^i * ct_i in a plaintext space of m bits (notes/Boolean Gates.md:2-11), and a gate's output
+is a fresh encryption of a bit, so gates chain.  This module evaluates a whole graph of such gates
+with every ciphertext staying in HBM: wires live in one device tensor, each level's gates that
+share a truth table go to the GPU as ONE batched call of the C ABI.
+
+Gate kinds
+  and / or / nand / nor / xor / xnor   one PBS (tfhe_gate_batch_device)
+  not                                  no PBS: (-a, enc(1) - b) (tfhe_lwe_not_batch_device)
+  mux(sel, a, b) = sel ? a : b         two PBS and one addition at any log_p >= 2:
+                                       AND(sel, a) + AND(NOT sel, b) -- the two terms are never both
+                                       1, so their sum already encodes the OR
+  lut(truth, x_{m-1}, ..., x_0)        one PBS of m inputs; needs a context with log_p >= m
 """
 from __future__ import annotations
 
 from dataclasses import dataclass, field
-from typing import Dict, List, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 TRUTH = {  # truth[(lhs << 1) | rhs], lhs = bit of ct1, rhs = bit of ct0 (boolean.rs:18)
     "and": (0, 0, 0, 1),
@@ -20,18 +29,38 @@ TRUTH = {  # truth[(lhs << 1) | rhs], lhs = bit of ct1, rhs = bit of ct0 (boolea
     "xor": (0, 1, 1, 0),
     "xnor": (1, 0, 0, 1),
 }
+_ANDNOT = (0, 1, 0, 0)  # (NOT lhs) AND rhs
 
 
 @dataclass
 class Circuit:
-    """Wires 0..n_inputs-1 are the inputs; every gate appends one wire."""
+    """Wires 0..n_inputs-1 are the inputs; every gate appends one wire.  A two-input gate is the
+    tuple (kind, wire of ct1, wire of ct0); `not` is (kind, wire), `mux` (kind, sel, a, b) and `lut`
+    (kind, operands most significant first..., ) with its truth table in `luts[gate index]`."""
     n_inputs: int
-    gates: List[Tuple[str, int, int]] = field(default_factory=list)  # (kind, wire of ct1, wire of ct0)
+    gates: List[Tuple] = field(default_factory=list)
+    luts: Dict[int, Tuple[int, ...]] = field(default_factory=dict)
+
+    def _add(self, entry: Tuple) -> int:
+        assert max(entry[1:]) < self.n_wires
+        self.gates.append(entry)
+        return self.n_wires - 1
 
     def gate(self, kind: str, lhs: int, rhs: int) -> int:
-        assert kind in TRUTH and max(lhs, rhs) < self.n_wires
-        self.gates.append((kind, lhs, rhs))
-        return self.n_wires - 1
+        assert kind in TRUTH
+        return self._add((kind, lhs, rhs))
+
+    def not_(self, a: int) -> int:
+        return self._add(("not", a))
+
+    def mux(self, sel: int, a: int, b: int) -> int:
+        return self._add(("mux", sel, a, b))
+
+    def lut(self, truth: Sequence[int], *operands: int) -> int:
+        """operands[0] is the leftmost (most significant) input: truth[(x_{m-1} ... x_0)_2]."""
+        assert len(truth) == 1 << len(operands)
+        self.luts[len(self.gates)] = tuple(int(v) for v in truth)
+        return self._add(("lut",) + tuple(operands))
 
     @property
     def n_wires(self) -> int:
@@ -41,16 +70,27 @@ class Circuit:
         """Gate indices grouped by depth (a gate's level = 1 + max level of its operands)."""
         depth = [0] * self.n_inputs
         by_level: Dict[int, List[int]] = {}
-        for g, (_, a, b) in enumerate(self.gates):
-            d = 1 + max(depth[a], depth[b])
+        for g, entry in enumerate(self.gates):
+            d = 1 + max(depth[w] for w in entry[1:])
             depth.append(d)
             by_level.setdefault(d, []).append(g)
         return [by_level[d] for d in sorted(by_level)]
 
     def evaluate_clear(self, bits: Sequence[int]) -> List[int]:
         w = list(bits)
-        for kind, a, b in self.gates:
-            w.append(TRUTH[kind][(w[a] << 1) | w[b]])
+        for g, entry in enumerate(self.gates):
+            kind, ops = entry[0], entry[1:]
+            if kind == "not":
+                w.append(1 - w[ops[0]])
+            elif kind == "mux":
+                w.append(w[ops[1]] if w[ops[0]] else w[ops[2]])
+            elif kind == "lut":
+                idx = 0
+                for o in ops:
+                    idx = (idx << 1) | w[o]
+                w.append(self.luts[g][idx])
+            else:
+                w.append(TRUTH[kind][(w[ops[0]] << 1) | w[ops[1]]])
         return w
 
 
@@ -75,26 +115,62 @@ def ripple_carry_adder(width: int) -> Tuple[Circuit, List[int]]:
     return c, out
 
 
+def full_adder_lut3(width: int) -> Tuple[Circuit, List[int]]:
+    """The same adder with three-input gates (needs log_p >= 3): sum = XOR3, carry = MAJ3 -- two
+    bootstraps per bit instead of five."""
+    xor3 = tuple((i ^ (i >> 1) ^ (i >> 2)) & 1 for i in range(8))
+    maj3 = tuple(1 if bin(i).count("1") >= 2 else 0 for i in range(8))
+    c = Circuit(2 * width)
+    out = []
+    carry: Optional[int] = None
+    for i in range(width):
+        a, b = i, width + i
+        if carry is None:
+            out.append(c.gate("xor", a, b))
+            carry = c.gate("and", a, b)
+        else:
+            out.append(c.lut(xor3, a, b, carry))
+            carry = c.lut(maj3, a, b, carry)
+    out.append(carry)
+    return c, out
+
+
 def evaluate(ctx, circuit: Circuit, inputs):
     """inputs: device tensor [instances][n_inputs][n+1] (32-bit) of LWE encryptions of bits, one row
     of wires per independent instance of the circuit.  Returns [instances][n_wires][n+1] on the
     same device.  All instances advance level by level; per level and truth table one batched gate
-    call covers instances x gates ciphertext pairs."""
+    call covers instances x gates ciphertexts."""
     import torch
     inst, n_in, width = inputs.shape
     assert n_in == circuit.n_inputs and width == ctx.params.n + 1
-    wires = torch.empty((inst, circuit.n_wires, width), dtype=inputs.dtype, device=inputs.device)
+    dev = inputs.device
+    wires = torch.empty((inst, circuit.n_wires, width), dtype=inputs.dtype, device=dev)
     wires[:, :n_in] = inputs
+
+    def operand(gs, pos):
+        idx = torch.tensor([circuit.gates[g][pos] for g in gs], device=dev)
+        return wires.index_select(1, idx).reshape(-1, width).contiguous()
+
     for level in circuit.levels():
-        by_kind: Dict[str, List[int]] = {}
+        groups: Dict[Tuple, List[int]] = {}
         for g in level:
-            by_kind.setdefault(circuit.gates[g][0], []).append(g)
-        for kind, gs in by_kind.items():
-            lhs = torch.tensor([circuit.gates[g][1] for g in gs], device=inputs.device)
-            rhs = torch.tensor([circuit.gates[g][2] for g in gs], device=inputs.device)
-            dst = torch.tensor([circuit.n_inputs + g for g in gs], device=inputs.device)
-            ct1 = wires.index_select(1, lhs).reshape(-1, width).contiguous()
-            ct0 = wires.index_select(1, rhs).reshape(-1, width).contiguous()
-            out = ctx.gate(TRUTH[kind], ct0, ct1)
+            kind = circuit.gates[g][0]
+            key = (kind, len(circuit.gates[g]) - 1, circuit.luts.get(g))
+            groups.setdefault(key, []).append(g)
+        for (kind, arity, truth), gs in groups.items():
+            dst = torch.tensor([circuit.n_inputs + g for g in gs], device=dev)
+            if kind == "not":
+                out = ctx.lwe_not(operand(gs, 1))
+            elif kind == "mux":
+                sel, a, b = operand(gs, 1), operand(gs, 2), operand(gs, 3)
+                t1 = ctx.gate(TRUTH["and"], a, sel)
+                t2 = ctx.gate(_ANDNOT, b, sel)
+                out = ctx.lwe_linear(1, t1, 1, t2)
+            elif kind == "lut":
+                # operands are listed most significant first; the ABI takes cts[0] = least significant
+                cts = [operand(gs, pos) for pos in range(arity, 0, -1)]
+                out = ctx.lut_gate(truth, cts)
+            else:
+                out = ctx.gate(TRUTH[kind], operand(gs, 2), operand(gs, 1))
             wires[:, dst] = out.reshape(inst, len(gs), width)
     return wires
