@@ -140,6 +140,12 @@ class Engine {
     check(tfhe_load_bootstrapping_key(ctx_.get(), flat.data(), bk.ksk.data.data()));
   }
 
+  // Extensions beyond the reference (tfhe_hip.h): the aligned decomposer for bases with
+  // beta^l != q, and the key-switch-then-PBS order of notes/TFHE.md:367-400 (ciphertexts of
+  // k*N+1 words at the boundary).  Defaults are the reference's behaviour.
+  void set_decomposer_alignment(bool aligned) { check(tfhe_context_set_decomposer_alignment(ctx_.get(), aligned)); }
+  void set_bootstrap_order(bool ks_first) { check(tfhe_context_set_bootstrap_order(ctx_.get(), ks_first)); }
+
   const TfheParams& params() const { return params_; }
   tfhe_context* raw() const { return ctx_.get(); }
   void check(int st) const {

@@ -260,6 +260,28 @@ int tfhe_bootstrapping_key_gen_device(tfhe_context *ctx, const uint32_t *lwe_sk,
                                       const uint32_t *glwe_sk, uint32_t *bsk, uint32_t *ksk,
                                       int load);
 
+/* ---- bootstrap order --------------------------------------------------------------
+ * 0 (default): the reference's order, PBS then key switch (bootstrapping.rs:58-120): ciphertexts at
+ * the boundary have n+1 words.
+ * 1: key switch first (notes/TFHE.md:367-400): input [batch][k*N+1] -> key_switch_lwe -> blind
+ * rotation -> sample_extract -> output [batch][k*N+1]; linear combinations between bootstraps then
+ * amplify only the PBS noise, not PBS + key-switch noise.  tfhe_bootstrap_batch*, tfhe_gate_batch*,
+ * tfhe_lut_gate_batch* and tfhe_lwe_not_batch* all use the selected boundary dimension; the same
+ * keys serve both orders. */
+int tfhe_context_set_bootstrap_order(tfhe_context *ctx, int ks_first);
+
+/* ---- decomposer alignment ------------------------------------------------------
+ * 0 (default): the reference's literal decomposer -- limbs counted from bit 0 (decomposer.rs:48-70),
+ * gadget factors beta^{floor(32/log_base)-(level+1)} (ggsw.rs:98, key_switching.rs:38), bit-exact
+ * with the crate; when log_base does not divide 32 the top 32 mod log_base bits are never
+ * represented, so such parameter sets do not decrypt (the reference's notes leave beta^l != q as a
+ * TODO, notes/TFHE.md:116,407).
+ * 1: aligned -- limbs and gadget factors counted down from bit 32 (factor 2^{32-log_base*(level+1)}),
+ * which makes e.g. log_base = 7, levels = 3 a working parameter set.  Applies to both decomposers,
+ * to the hot path and to keygen; identical bits to mode 0 whenever log_base divides 32.  Keys made
+ * in one mode must be used in that mode. */
+int tfhe_context_set_decomposer_alignment(tfhe_context *ctx, int aligned);
+
 /* ---- introspection for benchmarks --------------------------------------------------------- */
 /* Time of the blind-rotation kernel of the most recent bootstrap/blind_rotate call, measured with
  * HIP events on the context's stream (milliseconds); negative if none was recorded.  Enable with

@@ -151,6 +151,7 @@ def lib():
         _lib.orc_integer_division.restype = C.c_uint32
         _lib.orc_decrypt_lwe.restype = C.c_uint32
         _lib.orc_sample_gaussian.restype = C.c_uint32
+        _lib.orc_gadget_shift.restype = C.c_uint32
         _lib.orc_lwe_decode.restype = C.c_uint32
         _lib.orc_rng_next_u64.restype = C.c_uint64
         _lib.orc_rng_next_u32.restype = C.c_uint32
@@ -170,6 +171,38 @@ def _p(x: np.ndarray):
 def set_poly_mul_mode(mode: int) -> None:
     """0 = literal Toeplitz matrix + mat-vec (utils.rs:155-160); 1 = schoolbook (utils.rs:221-236)."""
     lib().orc_set_poly_mul_mode(C.c_int(mode))
+
+
+def set_decomposer_aligned(aligned: bool) -> None:
+    """False = the reference's literal decomposer; True = the aligned extension (tfhe_oracle.h)."""
+    lib().orc_set_decomposer_aligned(C.c_int(int(aligned)))
+
+
+class decomposer_aligned:
+    """with oracle.decomposer_aligned(True): ...  (restores the previous mode)"""
+
+    def __init__(self, aligned: bool):
+        self.aligned = aligned
+
+    def __enter__(self):
+        self.prev = lib().orc_get_decomposer_aligned()
+        set_decomposer_aligned(self.aligned)
+
+    def __exit__(self, *exc):
+        set_decomposer_aligned(bool(self.prev))
+
+
+def gadget_shift(dec: Decomposer, level: int) -> int:
+    cd = dec.to_c()
+    return int(lib().orc_gadget_shift(C.byref(cd), C.c_uint32(level)))
+
+
+def bootstrap_ks_first(params: Params, lwe_big, bsk, ksk, test_vector_poly) -> np.ndarray:
+    """The swapped order of notes/TFHE.md:367-400 composed from the reference's own steps:
+    key_switch_lwe (key_switching.rs:63-103) -> blind rotation (bootstrapping.rs:67-105) ->
+    sample_extract (bootstrapping.rs:122-156).  [k*N+1] -> [k*N+1]."""
+    small = key_switch_lwe(lwe_big, params.big_n, params.n, params.ks, ksk)
+    return sample_extract(params, blind_rotate(params, small, bsk, test_vector_poly), 0)
 
 
 def validate(params: Params) -> int:

@@ -71,6 +71,19 @@ void orc_params_default(orc_params *p, int cfg_test) {
 /* ------------------------------------------------------------------ decomposer.rs */
 
 /* decomposer.rs:27-40 */
+/* 0 (default) = the reference's literal decomposer.  1 = "aligned" extension for bases with
+ * beta^l != q (notes/TFHE.md:116,407 leave it as a TODO): gadget factors q/beta^(level+1) and limbs
+ * taken from the top of the word, so that a base whose log does not divide 32 still recomposes.
+ * Identical to the literal decomposer whenever log_base divides log_q. */
+static int g_decomposer_aligned = 0;
+void orc_set_decomposer_aligned(int aligned) { g_decomposer_aligned = aligned != 0; }
+int orc_get_decomposer_aligned(void) { return g_decomposer_aligned; }
+/* bit position of the gadget factor of `level` (MSB-first): factor = 1 << orc_gadget_shift() */
+uint32_t orc_gadget_shift(const orc_decomposer *d, uint32_t level) {
+    uint32_t top = g_decomposer_aligned ? d->log_q : d->log_base * (d->log_q / d->log_base);
+    return top - d->log_base * (level + 1);
+}
+
 uint32_t orc_round_value(const orc_decomposer *d, uint32_t value) {
     uint32_t ignored_bits = d->log_q - d->log_base * d->levels;
     if (ignored_bits == 0) return value;
@@ -93,8 +106,12 @@ int orc_decompose(const orc_decomposer *d, uint32_t value, uint32_t *out) {
     uint32_t base_mask = ((uint32_t)1 << log_base) - 1;
     uint32_t base_by_2_mask = (uint32_t)1 << (log_base - 1);
     uint32_t carry = 0;
-    for (uint32_t l = 0; l < d->log_q / d->log_base; ++l) {
-        uint32_t res = ((value >> (log_base * l)) & base_mask) + carry;
+    /* literal: limbs at bit log_base*l for all floor(log_q/log_base) limbs.  Aligned extension
+     * (NOT the reference): the `levels` kept limbs sit directly below bit log_q. */
+    uint32_t n_limbs = g_decomposer_aligned ? d->levels : d->log_q / d->log_base;
+    uint32_t bit0 = g_decomposer_aligned ? d->log_q - d->log_base * d->levels : 0;
+    for (uint32_t l = 0; l < n_limbs; ++l) {
+        uint32_t res = ((value >> (bit0 + log_base * l)) & base_mask) + carry;
         uint32_t carry_mask = res & base_by_2_mask;
         res = res - (carry_mask << 1);
         carry = carry_mask >> (log_base - 1);

@@ -60,6 +60,13 @@ void orc_params_default(orc_params *p, int cfg_test);
 /* poly_mul strategy: 0 = literal (materialise the N x N Toeplitz matrix, then mat-vec, as
  * utils.rs:155-160 does); 1 = schoolbook negacyclic (utils.rs:221-236), same bits, no matrix. */
 void orc_set_poly_mul_mode(int mode);
+/* Decomposer alignment: 0 (default) = the reference's literal decomposer (decomposer.rs:42-80,
+ * gadget factors beta^{floor(32/log_base)-(level+1)}); 1 = aligned extension, NOT in the reference
+ * (its notes leave beta^l != q as a TODO, notes/TFHE.md:116,407): limbs and gadget factors counted
+ * down from bit 32.  Both agree whenever log_base divides 32. */
+void orc_set_decomposer_aligned(int aligned);
+int orc_get_decomposer_aligned(void);
+uint32_t orc_gadget_shift(const orc_decomposer *d, uint32_t level);
 int orc_get_poly_mul_mode(void);
 
 /* ---- decomposer.rs ---- */

@@ -180,15 +180,15 @@ static void ggsw_rows(const orc_params *p, uint32_t message, const uint32_t *glw
     size_t n = degree_of(p);
     size_t k1 = p->glwe_dimension + 1;
     const orc_decomposer *d = &p->pbs_decomposer;
-    uint32_t log_q_by_log_base = p->log_q / d->log_base;
     for (size_t i = 0; i < k1; ++i) {
         for (uint32_t level_index = 0; level_index < d->levels; ++level_index) {
             uint32_t *row = ggsw + (i * d->levels + level_index) * k1 * n;
             if (r) orc_encrypt_glwe_zero(p, glwe_sk, r, row);
             else orc_encrypt_glwe_zero_from_samples(p, glwe_sk, row);
             if (message != 0) {
-                uint32_t decomposition_factor =
-                    message * ((uint32_t)1 << (d->log_base * (log_q_by_log_base - (level_index + 1))));
+                /* m * beta^{l-(level_index+1)} (ggsw.rs:96-99); orc_gadget_shift is that exponent
+                 * in literal mode */
+                uint32_t decomposition_factor = message * ((uint32_t)1 << orc_gadget_shift(d, level_index));
                 row[i * n + 0] += decomposition_factor;
             }
         }
@@ -210,10 +210,9 @@ void orc_encrypt_ggsw_from_samples(const orc_params *p, uint32_t message, const 
  * s_bit * 2^{log_base*(l - (level+1))} added to the b slot */
 static void ksk_rows(const uint32_t *from_sk, size_t from_n, const uint32_t *to_sk, size_t to_n,
                      double to_std_dev, const orc_decomposer *d, orc_rng *r, uint32_t *ksk) {
-    uint32_t l = d->log_q / d->log_base;
     for (size_t s_index = 0; s_index < from_n; ++s_index) {
         for (uint32_t level_index = 0; level_index < d->levels; ++level_index) {
-            uint32_t factor = (uint32_t)1 << (d->log_base * (l - (level_index + 1)));
+            uint32_t factor = (uint32_t)1 << orc_gadget_shift(d, level_index); /* beta^{l-(level+1)} */
             factor *= from_sk[s_index];
             uint32_t *row = ksk + (s_index * d->levels + level_index) * (to_n + 1);
             if (r) orc_encrypt_lwe_plaintext(to_n, to_std_dev, to_sk, 0u, r, row);

@@ -146,6 +146,8 @@ void glwe_body(u32 k, size_t rows, const u32* glwe, const u32* sk, u32* out, int
   });
 }
 
+bool g_aligned = false;  // decomposer alignment extension (tfhe_hip.h)
+
 PbsParams make_params(u32 n, u32 k, u32 log_n, u32 log_p, u32 padding, u32 log_base, u32 levels) {
   PbsParams P;
   P.n = n;
@@ -155,7 +157,7 @@ PbsParams make_params(u32 n, u32 k, u32 log_n, u32 log_p, u32 padding, u32 log_b
   P.log_base = log_base;
   P.levels = levels;
   P.ignored_bits = 32 - log_base * levels;
-  P.first_shift = log_base * (32 / log_base - levels);
+  P.first_shift = (g_aligned ? 32u : log_base * (32 / log_base)) - log_base * levels;
   return P;
 }
 
@@ -178,6 +180,7 @@ PbsParams make_params(u32 n, u32 k, u32 log_n, u32 log_p, u32 padding, u32 log_b
 
 extern "C" {
 
+void emu_set_aligned(int aligned) { g_aligned = aligned != 0; }
 int emu_field_parts(int field) { return field == 1 ? 1 : 2; }
 
 int emu_poly_ntt(int field, int logn, int g, const void* in, void* out, int inverse) {

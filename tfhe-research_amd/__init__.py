@@ -249,6 +249,23 @@ class Context:
     def backend(self) -> str:
         return lib().tfhe_context_backend(self._h).decode()
 
+    # -- extensions beyond the reference -------------------------------------------
+    def set_decomposer_alignment(self, aligned: bool):
+        """False: the reference's literal decomposer (bit-exact with the crate).  True: limbs and
+        gadget factors counted down from bit 32, so bases with log_base not dividing 32 decrypt."""
+        self._check(lib().tfhe_context_set_decomposer_alignment(self._h, C.c_int(int(aligned))))
+
+    def set_bootstrap_order(self, ks_first: bool):
+        """False: PBS then key switch (bootstrapping.rs:58-120), ciphertexts of n+1 words.  True:
+        key switch then PBS (notes/TFHE.md:367-400), ciphertexts of k*N+1 words."""
+        self._check(lib().tfhe_context_set_bootstrap_order(self._h, C.c_int(int(ks_first))))
+        self._ks_first = bool(ks_first)
+
+    @property
+    def io_dim(self) -> int:
+        """LWE dimension of ciphertexts at the bootstrap / gate boundary"""
+        return self.params.big_n if getattr(self, "_ks_first", False) else self.params.n
+
     def prepared_ggsw_words(self) -> int:
         w = C.c_size_t()
         self._check(lib().tfhe_prepared_ggsw_words(self._h, C.byref(w)))
@@ -303,7 +320,7 @@ class Context:
         if _is_torch(lwe_in):
             import torch
             batch = lwe_in.shape[0]
-            assert lwe_in.shape[1] == p.n + 1
+            assert lwe_in.shape[1] == self.io_dim + 1
             if out is None:
                 out = torch.empty_like(lwe_in)
             self._check(lib().tfhe_bootstrap_batch_device(
@@ -312,7 +329,7 @@ class Context:
             return out
         lwe_in, tv = _np(lwe_in), _np(test_vector_poly)
         single = lwe_in.ndim == 1
-        lwe2 = lwe_in.reshape(-1, p.n + 1)
+        lwe2 = lwe_in.reshape(-1, self.io_dim + 1)
         res = np.zeros_like(lwe2)
         self._check(lib().tfhe_bootstrap_batch(self._h, _hp(lwe2), C.c_size_t(lwe2.shape[0]), _hp(tv),
                                                C.c_size_t(self._tv_count(tv, lwe2.shape[0])), _hp(res)))
@@ -466,13 +483,13 @@ class Context:
             import torch
             batch = cts[0].shape[0]
             for i, t in enumerate(cts):
-                assert tuple(t.shape) == (batch, p.n + 1)
+                assert tuple(t.shape) == (batch, self.io_dim + 1)
                 ptrs[i] = _dp(t)
             if out is None:
                 out = torch.empty_like(cts[0])
             self._check(lib().tfhe_lut_gate_batch_device(self._h, arr, C.c_uint32(m), ptrs, C.c_size_t(batch), _dp(out)))
             return out
-        host = [_np(t).reshape(-1, p.n + 1) for t in cts]
+        host = [_np(t).reshape(-1, self.io_dim + 1) for t in cts]
         for i, t in enumerate(host):
             assert t.shape == host[0].shape
             ptrs[i] = _hp(t)
@@ -487,10 +504,10 @@ class Context:
             import torch
             if out is None:
                 out = torch.empty_like(ct)
-            self._check(lib().tfhe_lwe_not_batch_device(self._h, _dp(ct), C.c_size_t(ct.numel() // (p.n + 1)), _dp(out)))
+            self._check(lib().tfhe_lwe_not_batch_device(self._h, _dp(ct), C.c_size_t(ct.numel() // (self.io_dim + 1)), _dp(out)))
             return out
         a = _np(ct)
-        rows = a.reshape(-1, p.n + 1)
+        rows = a.reshape(-1, self.io_dim + 1)
         res = np.zeros_like(rows)
         self._check(lib().tfhe_lwe_not_batch(self._h, _hp(rows), C.c_size_t(rows.shape[0]), _hp(res)))
         return res.reshape(a.shape)
@@ -506,7 +523,7 @@ class Context:
                 out = torch.empty_like(ct0)
             self._check(lib().tfhe_gate_batch_device(self._h, arr, _dp(ct0), _dp(ct1), C.c_size_t(batch), _dp(out)))
             return out
-        a, b = _np(ct0).reshape(-1, p.n + 1), _np(ct1).reshape(-1, p.n + 1)
+        a, b = _np(ct0).reshape(-1, self.io_dim + 1), _np(ct1).reshape(-1, self.io_dim + 1)
         res = np.zeros_like(a)
         self._check(lib().tfhe_gate_batch(self._h, arr, _hp(a), _hp(b), C.c_size_t(a.shape[0]), _hp(res)))
         return res

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -34,6 +35,8 @@ struct tfhe_context {
   void* d_bsk = nullptr;      // prepared BSK [n][R][k+1][parts][N] (spectrum_slot order, x 1/N)
   u32* d_ksk = nullptr;       // [big_n*l_ks][n+1]
   bool have_key = false;
+  bool aligned = false;       // decomposer alignment (tfhe_context_set_decomposer_alignment)
+  bool ks_first = false;      // bootstrap order (tfhe_context_set_bootstrap_order)
 
   // workspace (grown on demand by host-pointer calls or tfhe_context_reserve)
   size_t ws_batch = 0;
@@ -41,6 +44,7 @@ struct tfhe_context {
   u32* d_lwe_in2 = nullptr;   // [batch][n+1] second gate operand
   u32* d_lwe_big = nullptr;   // [batch][big_n+1]
   u32* d_lwe_out = nullptr;   // [batch][n+1]
+  u32* d_lwe_ks = nullptr;    // [batch][n+1] key-switched input of the KS-then-PBS order
   u32* d_glwe_a = nullptr;    // [batch][k+1][N]
   u32* d_glwe_b = nullptr;
   u32* d_glwe_c = nullptr;
@@ -81,6 +85,13 @@ int hip_fail(tfhe_context* ctx, hipError_t e, const char* what) {
     if (_e != hipSuccess) return hip_fail((ctx), _e, #expr);      \
   } while (0)
 
+// Bit just above the most significant limb: gadget factor of level i is 2^{top - log_base*(i+1)} and
+// the lowest kept limb starts at top - log_base*levels.  Literal (reference, decomposer.rs:48-70 /
+// ggsw.rs:98): limbs are counted from bit 0, so top = log_base*floor(32/log_base).  Aligned: 32.
+u32 gadget_top(const tfhe_context* ctx, u32 log_base) {
+  return ctx->aligned ? 32u : log_base * (32u / log_base);
+}
+
 int decomposer_validate(const tfhe_decomposer_params& d) {
   if (d.log_q != 32) return 1;                        // the reference is hard-typed to u32
   if (d.log_base == 0 || d.log_base >= 32) return 2;  // 1 << (log_base - 1), 1 << log_base
@@ -103,14 +114,16 @@ int ensure(tfhe_context* ctx, T** ptr, size_t* have, size_t want_elems) {
 
 int reserve(tfhe_context* ctx, size_t batch) {
   if (batch <= ctx->ws_batch) return TFHE_OK;
-  const size_t n1 = (size_t)ctx->params.lwe_dimension + 1;
+  // every LWE buffer can hold either boundary dimension (n for the reference's PBS-then-KS order,
+  // k*N for KS-then-PBS), so switching the order never reallocates
+  const size_t n1 = std::max((size_t)ctx->params.lwe_dimension, (size_t)ctx->big_n) + 1;
   const size_t glwe = (size_t)(ctx->params.glwe_dimension + 1) * ctx->N;
-  u32** ptrs[] = {&ctx->d_lwe_in, &ctx->d_lwe_in2, &ctx->d_lwe_big, &ctx->d_lwe_out,
+  u32** ptrs[] = {&ctx->d_lwe_in, &ctx->d_lwe_in2, &ctx->d_lwe_big, &ctx->d_lwe_out, &ctx->d_lwe_ks,
                   &ctx->d_glwe_a, &ctx->d_glwe_b,   &ctx->d_glwe_c,  &ctx->d_tv};
-  const size_t sizes[] = {batch * n1, batch * n1, batch * ((size_t)ctx->big_n + 1), batch * n1,
+  const size_t sizes[] = {batch * n1, batch * n1, batch * n1, batch * n1, batch * n1,
                           batch * glwe, batch * glwe, batch * glwe, batch * ctx->N};
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < 9; ++i) {
     if (*ptrs[i]) HIP_TRY(ctx, hipFree(*ptrs[i]));
     *ptrs[i] = nullptr;
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(ptrs[i]), sizes[i] * sizeof(u32)));
@@ -165,21 +178,36 @@ int check_tv_host(tfhe_context* ctx, const u32* tv, size_t words) {
 }
 
 // Enqueue the whole PBS on device buffers: blind rotation (+ fused sample extract), key switch.
+// words of one ciphertext at the bootstrap boundary: n+1 in the reference's order (PBS then KS,
+// bootstrapping.rs:58-120), k*N+1 when the key switch comes first
+size_t io_words(const tfhe_context* ctx) {
+  return (ctx->ks_first ? (size_t)ctx->big_n : (size_t)ctx->params.lwe_dimension) + 1;
+}
+
+// d_lwe_big: [batch][k*N+1] scratch of the reference order (unused when the key switch comes first)
 int enqueue_bootstrap(tfhe_context* ctx, const u32* d_lwe_in, size_t batch, const u32* d_tv,
                       size_t tv_count, u32* d_lwe_big, u32* d_lwe_out) {
+  const u32* br_in = d_lwe_in;
+  u32* br_out = d_lwe_big;
+  if (ctx->ks_first) {  // notes/TFHE.md:367-400: key switch k*N -> n, then PBS back to k*N
+    if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    HIP_TRY(ctx, launch::key_switch(ctx->stream, ctx->ks, ctx->big_n, ctx->params.lwe_dimension,
+                                    d_lwe_in, batch, ctx->d_ksk, ctx->d_lwe_ks));
+    if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    br_in = ctx->d_lwe_ks;
+    br_out = d_lwe_out;
+  }
   if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-  HIP_TRY(ctx, launch::blind_rotate(ctx->stream, ctx->field, ctx->pbs, ctx->d_tw, d_lwe_in, batch, d_tv,
-                                    tv_count == 1 ? 0 : ctx->N, ctx->d_bsk, nullptr, d_lwe_big));
-  if (ctx->timing) {
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+  HIP_TRY(ctx, launch::blind_rotate(ctx->stream, ctx->field, ctx->pbs, ctx->d_tw, br_in, batch, d_tv,
+                                    tv_count == 1 ? 0 : ctx->N, ctx->d_bsk, nullptr, br_out));
+  if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+  if (!ctx->ks_first) {
+    if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    HIP_TRY(ctx, launch::key_switch(ctx->stream, ctx->ks, ctx->big_n, ctx->params.lwe_dimension,
+                                    d_lwe_big, batch, ctx->d_ksk, d_lwe_out));
+    if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
   }
-  HIP_TRY(ctx, launch::key_switch(ctx->stream, ctx->ks, ctx->big_n, ctx->params.lwe_dimension,
-                                  d_lwe_big, batch, ctx->d_ksk, d_lwe_out));
-  if (ctx->timing) {
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
-    ctx->ev_valid_br = ctx->ev_valid_ks = true;
-  }
+  if (ctx->timing) ctx->ev_valid_br = ctx->ev_valid_ks = true;
   return TFHE_OK;
 }
 
@@ -308,11 +336,11 @@ int tfhe_context_create_with_backend(const tfhe_params* params, int device, int 
   ctx->pbs.log_base = params->pbs_decomposer.log_base;
   ctx->pbs.levels = params->pbs_decomposer.levels;
   ctx->pbs.ignored_bits = 32 - ctx->pbs.log_base * ctx->pbs.levels;
-  ctx->pbs.first_shift = ctx->pbs.log_base * (32 / ctx->pbs.log_base - ctx->pbs.levels);
+  ctx->pbs.first_shift = gadget_top(ctx, ctx->pbs.log_base) - ctx->pbs.log_base * ctx->pbs.levels;
   ctx->ks.log_base = params->ks_decomposer.log_base;
   ctx->ks.levels = params->ks_decomposer.levels;
   ctx->ks.ignored_bits = 32 - ctx->ks.log_base * ctx->ks.levels;
-  ctx->ks.first_shift = ctx->ks.log_base * (32 / ctx->ks.log_base - ctx->ks.levels);
+  ctx->ks.first_shift = gadget_top(ctx, ctx->ks.log_base) - ctx->ks.log_base * ctx->ks.levels;
 
   auto bail = [&](hipError_t e, const char* what) {
     std::fprintf(stderr, "tfhe_context_create: %s: %s\n", what, hipGetErrorString(e));
@@ -355,7 +383,7 @@ void tfhe_context_destroy(tfhe_context* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   void* ptrs[] = {ctx->d_tw,     ctx->d_bsk,    ctx->d_ksk,    ctx->d_lwe_in, ctx->d_lwe_in2,
-                  ctx->d_lwe_big, ctx->d_lwe_out, ctx->d_glwe_a, ctx->d_glwe_b, ctx->d_glwe_c,
+                  ctx->d_lwe_big, ctx->d_lwe_out, ctx->d_lwe_ks, ctx->d_glwe_a, ctx->d_glwe_b, ctx->d_glwe_c,
                   ctx->d_tv,     ctx->d_tv_gate, ctx->d_misc,   ctx->d_ggsw_tmp, ctx->d_ggsw_raw,
                   ctx->d_key_tmp};
   for (void* p : ptrs)
@@ -385,6 +413,24 @@ int tfhe_context_use_own_stream(tfhe_context* ctx) {
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   ctx->own_stream = true;
+  return TFHE_OK;
+}
+
+int tfhe_context_set_decomposer_alignment(tfhe_context* ctx, int aligned) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->aligned = aligned != 0;
+  ctx->pbs.first_shift = gadget_top(ctx, ctx->pbs.log_base) - ctx->pbs.log_base * ctx->pbs.levels;
+  ctx->ks.first_shift = gadget_top(ctx, ctx->ks.log_base) - ctx->ks.log_base * ctx->ks.levels;
+  return TFHE_OK;
+}
+
+int tfhe_context_set_bootstrap_order(tfhe_context* ctx, int ks_first) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->ks_first = ks_first != 0;
   return TFHE_OK;
 }
 
@@ -490,7 +536,7 @@ int tfhe_bootstrap_batch(tfhe_context* ctx, const uint32_t* lwe_in, size_t batch
   if (!ctx->have_key) return fail(ctx, TFHE_ERR_NO_KEY, "load the bootstrapping key first");
   if ((st = check_tv_host(ctx, tv, tv_count * ctx->N))) return st;
   if ((st = reserve(ctx, batch))) return st;
-  const size_t n1 = (size_t)ctx->params.lwe_dimension + 1;
+  const size_t n1 = io_words(ctx);
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_lwe_in, lwe_in, batch * n1 * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_tv, tv, tv_count * ctx->N * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
   if ((st = enqueue_bootstrap(ctx, ctx->d_lwe_in, batch, ctx->d_tv, tv_count, ctx->d_lwe_big, ctx->d_lwe_out)))
@@ -676,7 +722,8 @@ int tfhe_decompose(tfhe_context* ctx, int which, const uint32_t* values, size_t 
   u32* d_in = reinterpret_cast<u32*>(ctx->d_misc);
   u32* d_out = d_in + count;
   HIP_TRY(ctx, hipMemcpyAsync(d_in, values, in_b, hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, launch::decompose_words(ctx->stream, d.log_base, d.levels, d_in, count, d_out));
+  HIP_TRY(ctx, launch::decompose_words(ctx->stream, d.log_base, d.levels,
+                                       gadget_top(ctx, d.log_base) - d.log_base * d.levels, d_in, count, d_out));
   HIP_TRY(ctx, hipMemcpyAsync(digits_out, d_out, out_b, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return TFHE_OK;
@@ -692,7 +739,7 @@ int tfhe_decompose_glwe_batch(tfhe_context* ctx, const uint32_t* glwe, size_t ba
   u32* d_in = reinterpret_cast<u32*>(ctx->d_misc);
   u32* d_out = d_in + in_w;
   HIP_TRY(ctx, hipMemcpyAsync(d_in, glwe, in_w * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, launch::decompose_glwe(ctx->stream, ctx->pbs.log_base, ctx->pbs.levels, polys, ctx->N, d_in, batch, d_out));
+  HIP_TRY(ctx, launch::decompose_glwe(ctx->stream, ctx->pbs.log_base, ctx->pbs.levels, ctx->pbs.first_shift, polys, ctx->N, d_in, batch, d_out));
   HIP_TRY(ctx, hipMemcpyAsync(digits_out, d_out, out_w * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return TFHE_OK;
@@ -803,13 +850,13 @@ int ksk_gen_device(tfhe_context* ctx, const u32* from_sk, size_t from_dim, const
                    size_t to_dim, u32* d_ksk) {
   int st;
   const u32 levels = ctx->ks.levels, log_base = ctx->ks.log_base;
-  const u32 l_full = 32 / log_base;
+  const u32 top = gadget_top(ctx, log_base);
   const size_t rows = from_dim * levels;
   // row s*levels + level carries s_bit * 2^{log_base*(l - (level+1))} in its b slot (:36-45)
   std::vector<u32> factor(rows);
   for (size_t s = 0; s < from_dim; ++s)
     for (u32 level = 0; level < levels; ++level)
-      factor[s * levels + level] = (1u << (log_base * (l_full - (level + 1)))) * from_sk[s];
+      factor[s * levels + level] = (1u << (top - log_base * (level + 1))) * from_sk[s];
   if ((st = ensure_key_tmp(ctx, to_dim + rows))) return st;
   if ((st = to_key_tmp(ctx, to_sk, to_dim, 0))) return st;
   if ((st = to_key_tmp(ctx, factor.data(), rows, to_dim))) return st;
@@ -882,7 +929,8 @@ int tfhe_ggsw_encrypt_batch_device(tfhe_context* ctx, const uint32_t* glwe_sk, c
   if ((st = to_key_tmp(ctx, messages, count, kn))) return st;
   if ((st = glwe_rows_add_mask_dot_key(ctx, ggsw, count * ctx->R))) return st;
   HIP_TRY(ctx, launch::ggsw_add_gadget(ctx->stream, ggsw, count, k, ctx->pbs.log_n, ctx->pbs.levels,
-                                       ctx->pbs.log_base, ctx->d_key_tmp + kn));
+                                       ctx->pbs.log_base, gadget_top(ctx, ctx->pbs.log_base),
+                                       ctx->d_key_tmp + kn));
   return TFHE_OK;
 }
 
@@ -1051,7 +1099,7 @@ static int lut_gate_device(tfhe_context* ctx, const u32* truth, u32 inputs, cons
     if (!cts[i]) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null input ciphertext");
   if (!ctx->have_key) return fail(ctx, TFHE_ERR_NO_KEY, "load the bootstrapping key first");
   if ((st = reserve(ctx, batch))) return st;
-  const size_t words = batch * ((size_t)ctx->params.lwe_dimension + 1);
+  const size_t words = batch * io_words(ctx);
   const u32 entries = 1u << inputs;
   if (ctx->gate_truth.size() != entries || std::memcmp(ctx->gate_truth.data(), truth, entries * sizeof(u32)) != 0) {
     // first use of this truth table: build its test vector on the host and upload it (this one
@@ -1096,7 +1144,7 @@ int tfhe_lut_gate_batch(tfhe_context* ctx, const uint32_t* truth, uint32_t input
   if (st) return st;
   if (!truth || !cts || !lwe_out || batch == 0 || inputs == 0 || inputs > 8)
     return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer / empty batch / bad input count");
-  const size_t words = batch * ((size_t)ctx->params.lwe_dimension + 1);
+  const size_t words = batch * io_words(ctx);
   if ((st = ensure_misc(ctx, (size_t)(inputs + 1) * words * sizeof(u32)))) return st;
   u32* d = reinterpret_cast<u32*>(ctx->d_misc);
   const u32* d_cts[8];
@@ -1124,7 +1172,7 @@ int tfhe_lwe_not_batch_device(tfhe_context* ctx, const uint32_t* ct, size_t batc
   int st = check_ctx(ctx);
   if (st) return st;
   if (!ct || !lwe_out || batch == 0) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer / empty batch");
-  const size_t n1 = (size_t)ctx->params.lwe_dimension + 1;
+  const size_t n1 = io_words(ctx);
   const u32 one = 1u << (32 - ctx->params.log_p - ctx->params.padding_bits);
   HIP_TRY(ctx, launch::lwe_linear(ctx->stream, 0xFFFFFFFFu, ct, 0u, nullptr, batch * n1, lwe_out, n1, one));
   return TFHE_OK;
@@ -1134,7 +1182,7 @@ int tfhe_lwe_not_batch(tfhe_context* ctx, const uint32_t* ct, size_t batch, uint
   int st = check_ctx(ctx);
   if (st) return st;
   if (!ct || !lwe_out || batch == 0) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer / empty batch");
-  const size_t words = batch * ((size_t)ctx->params.lwe_dimension + 1);
+  const size_t words = batch * io_words(ctx);
   if ((st = ensure_misc(ctx, 2 * words * sizeof(u32)))) return st;
   u32* d = reinterpret_cast<u32*>(ctx->d_misc);
   HIP_TRY(ctx, hipMemcpyAsync(d, ct, words * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));

@@ -446,19 +446,19 @@ __global__ void __launch_bounds__(256) lwe_body_kernel(const u32* rows, size_t r
 }
 
 // ggsw.rs:96-103: row = poly_index*levels + level of GGSW g gets
-// messages[g] * 2^{log_base*(floor(32/log_base) - (level+1))} added to coefficient 0 of polynomial
-// poly_index (after the zero encryption was formed from the unmodified masks)
+// messages[g] * 2^{gadget_top - log_base*(level+1)} added to coefficient 0 of polynomial poly_index
+// (after the zero encryption was formed from the unmodified masks); gadget_top =
+// log_base*floor(32/log_base) for the reference's literal decomposer
 __global__ void ggsw_add_gadget_kernel(u32* ggsw, size_t ggsw_count, u32 k, u32 log_n, u32 levels,
-                                       u32 log_base, const u32* __restrict__ messages) {
+                                       u32 log_base, u32 gadget_top, const u32* __restrict__ messages) {
   const size_t rows = (size_t)(k + 1) * levels;
   const size_t total = ggsw_count * rows;
-  const u32 l_full = 32 / log_base;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (size_t)gridDim.x * blockDim.x) {
     const size_t g = i / rows;
     const u32 row = (u32)(i % rows);
     const u32 poly_index = row / levels, level = row % levels;
-    const u32 factor = messages[g] * (1u << (log_base * (l_full - (level + 1))));
+    const u32 factor = messages[g] * (1u << (gadget_top - log_base * (level + 1)));
     ggsw[(((g * rows + row) * (k + 1)) + poly_index) << log_n] += factor;
   }
 }
@@ -649,24 +649,17 @@ hipError_t key_switch(hipStream_t s, const KsParams& K, u32 big_n, u32 n, const 
   return hipGetLastError();
 }
 
-static void decomposer_derived(u32 log_base, u32 levels, u32* ignored_bits, u32* first_shift) {
-  *ignored_bits = 32 - log_base * levels;
-  *first_shift = log_base * (32 / log_base - levels);
-}
-
-hipError_t decompose_words(hipStream_t s, u32 log_base, u32 levels, const u32* values, size_t count,
-                           u32* digits) {
-  u32 ig, fs;
-  decomposer_derived(log_base, levels, &ig, &fs);
+hipError_t decompose_words(hipStream_t s, u32 log_base, u32 levels, u32 fs, const u32* values,
+                           size_t count, u32* digits) {
+  const u32 ig = 32 - log_base * levels;
   hipLaunchKernelGGL(decompose_words_kernel, dim3(grid_for(count, 256)), dim3(256), 0, s, log_base,
                      levels, ig, fs, values, count, digits);
   return hipGetLastError();
 }
 
-hipError_t decompose_glwe(hipStream_t s, u32 log_base, u32 levels, u32 polys_per_ct, u32 n_coeff,
-                          const u32* glwe, size_t batch, u32* digits) {
-  u32 ig, fs;
-  decomposer_derived(log_base, levels, &ig, &fs);
+hipError_t decompose_glwe(hipStream_t s, u32 log_base, u32 levels, u32 fs, u32 polys_per_ct,
+                          u32 n_coeff, const u32* glwe, size_t batch, u32* digits) {
+  const u32 ig = 32 - log_base * levels;
   const size_t total = batch * polys_per_ct * n_coeff;
   hipLaunchKernelGGL(decompose_glwe_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, log_base,
                      levels, ig, fs, polys_per_ct, n_coeff, glwe, total, digits);
@@ -719,10 +712,10 @@ hipError_t lwe_body(hipStream_t s, const u32* rows, size_t row_count, u32 n, con
 }
 
 hipError_t ggsw_add_gadget(hipStream_t s, u32* ggsw, size_t ggsw_count, u32 k, u32 log_n, u32 levels,
-                           u32 log_base, const u32* messages) {
+                           u32 log_base, u32 gadget_top, const u32* messages) {
   const size_t total = ggsw_count * (size_t)(k + 1) * levels;
   hipLaunchKernelGGL(ggsw_add_gadget_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, ggsw,
-                     ggsw_count, k, log_n, levels, log_base, messages);
+                     ggsw_count, k, log_n, levels, log_base, gadget_top, messages);
   return hipGetLastError();
 }
 

@@ -40,11 +40,12 @@ hipError_t external_product(hipStream_t s, int field, const PbsParams& P, const 
 hipError_t key_switch(hipStream_t s, const KsParams& K, u32 big_n, u32 n, const u32* lwe_in,
                       size_t batch, const u32* ksk, u32* lwe_out);
 
-// elementwise helpers
-hipError_t decompose_words(hipStream_t s, u32 log_base, u32 levels, const u32* values, size_t count,
-                           u32* digits /* [count][levels] */);
-hipError_t decompose_glwe(hipStream_t s, u32 log_base, u32 levels, u32 polys_per_ct, u32 n_coeff,
-                          const u32* glwe, size_t batch, u32* digits /* [batch][polys*levels][N] */);
+// elementwise helpers.  first_shift = bit of the lowest kept limb (PbsParams::first_shift)
+hipError_t decompose_words(hipStream_t s, u32 log_base, u32 levels, u32 first_shift, const u32* values,
+                           size_t count, u32* digits /* [count][levels] */);
+hipError_t decompose_glwe(hipStream_t s, u32 log_base, u32 levels, u32 first_shift, u32 polys_per_ct,
+                          u32 n_coeff, const u32* glwe, size_t batch,
+                          u32* digits /* [batch][polys*levels][N] */);
 hipError_t switch_modulus(hipStream_t s, const u32* values, size_t count, u32 log_from, u32 log_to,
                           u32* out);
 hipError_t glwe_mul_monomial(hipStream_t s, u32 log_n, u32 polys_per_ct, const u32* glwe,
@@ -66,7 +67,7 @@ hipError_t lwe_body(hipStream_t s, const u32* rows, size_t row_count, u32 n, con
                     const u32* plaintext, u32* dst, size_t dst_stride, bool negate);
 // ggsw.rs:96-103 for ggsw_count matrices [(k+1)*levels][k+1][N]
 hipError_t ggsw_add_gadget(hipStream_t s, u32* ggsw, size_t ggsw_count, u32 k, u32 log_n, u32 levels,
-                           u32 log_base, const u32* messages);
+                           u32 log_base, u32 gadget_top, const u32* messages);
 
 }  // namespace launch
 }  // namespace tfhe

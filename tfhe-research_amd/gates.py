@@ -142,7 +142,7 @@ def evaluate(ctx, circuit: Circuit, inputs):
     call covers instances x gates ciphertexts."""
     import torch
     inst, n_in, width = inputs.shape
-    assert n_in == circuit.n_inputs and width == ctx.params.n + 1
+    assert n_in == circuit.n_inputs and width == ctx.io_dim + 1
     dev = inputs.device
     wires = torch.empty((inst, circuit.n_wires, width), dtype=inputs.dtype, device=dev)
     wires[:, :n_in] = inputs
