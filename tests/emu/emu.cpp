@@ -26,6 +26,7 @@ struct HostTeam {
   std::vector<u32> acc;
   pthread_barrier_t team_bar;
   std::vector<pthread_barrier_t> group_bars;
+  std::vector<pthread_barrier_t> wave_bars;  // lanes are free-running threads: lockstep = a barrier
 };
 
 template <class Elem>
@@ -35,6 +36,7 @@ struct HostWave {
   int tid() const { return (wave_ % t_->g) * 64 + lane_; }
   int group() const { return wave_ / t_->g; }
   void poly_sync() const { pthread_barrier_wait(&t_->group_bars[group()]); }
+  void wave_sync() const { pthread_barrier_wait(&t_->wave_bars[wave_]); }
   void team_sync() const { pthread_barrier_wait(&t_->team_bar); }
   Elem* scratch() const { return t_->scratch.data() + (size_t)group() * t_->n; }
   const Elem* scratch_of(int s) const { return t_->scratch.data() + (size_t)s * t_->n; }
@@ -59,6 +61,8 @@ void run_team(int logn, int groups, int g, const std::function<void(const HostWa
   pthread_barrier_init(&team.team_bar, nullptr, waves * kWave);
   team.group_bars.resize(groups);
   for (auto& b : team.group_bars) pthread_barrier_init(&b, nullptr, g * kWave);
+  team.wave_bars.resize(waves);
+  for (auto& b : team.wave_bars) pthread_barrier_init(&b, nullptr, kWave);
   std::vector<std::thread> th;
   for (int w = 0; w < waves; ++w)
     for (int l = 0; l < kWave; ++l)
@@ -163,12 +167,13 @@ PbsParams make_params(u32 n, u32 k, u32 log_n, u32 log_p, u32 padding, u32 log_b
 
 }  // namespace
 
-// (logn, g): g = waves per polynomial; supported: (9,1) (10,1) (11,1) (11,2)
+// (logn, g): g = waves per polynomial; supported: (9,1) (10,1) (11,1) (11,2) (11,4)
 #define DISPATCH_LOGN(logn, g, CALL)                                     \
   if ((logn) == 9 && (g) == 1) { constexpr int L = 9, GG = 1; CALL; }    \
   else if ((logn) == 10 && (g) == 1) { constexpr int L = 10, GG = 1; CALL; } \
   else if ((logn) == 11 && (g) == 1) { constexpr int L = 11, GG = 1; CALL; } \
   else if ((logn) == 11 && (g) == 2) { constexpr int L = 11, GG = 2; CALL; } \
+  else if ((logn) == 11 && (g) == 4) { constexpr int L = 11, GG = 4; CALL; } \
   else return 1;
 
 // field: 1 = Goldilocks, 2 = fp64 prime (double elements), 3 = Goldilocks with split key; 8-byte words

@@ -133,7 +133,7 @@ def test_fp_field_arithmetic(emu):
         assert (int(lo) + (int(hi) << 16) - word) % (1 << 32) == 0
 
 
-@pytest.mark.parametrize("logn,g", [(9, 1), (10, 1), (11, 1), (11, 2)])
+@pytest.mark.parametrize("logn,g", [(9, 1), (10, 1), (11, 1), (11, 2), (11, 4)])
 def test_fp_wave_ntt_roundtrip_and_convolution(emu, logn, g):
     """fp64 field transform: forward of two small polynomials, pointwise product, inverse = exact
     negacyclic convolution (checked with numpy integers)."""
@@ -174,7 +174,8 @@ CASES = [
     (1, 10, 3, (7, 3), 2, 1),   # BASELINE cfg2 shape, misaligned base (bits 28..31 dropped)
     (2, 9, 2, (4, 6), 2, 1),    # reference default shape
     (2, 11, 1, (8, 4), 4, 1),   # BASELINE cfg5 shape, one wave per polynomial
-    (2, 11, 1, (8, 4), 4, 2),   # BASELINE cfg5 shape, two waves per polynomial (the shipped mapping)
+    (2, 11, 1, (8, 4), 4, 2),   # BASELINE cfg5 shape, two waves per polynomial
+    (2, 11, 1, (8, 4), 4, 4),   # BASELINE cfg5 shape, four waves per polynomial (the shipped mapping)
     (1, 11, 2, (4, 7), 2, 2),
 ]
 
@@ -195,7 +196,7 @@ def test_external_product_vs_oracle(emu, oracle, field, k, logn, n, pbs, log_p, 
 
 
 @pytest.mark.parametrize("field", FIELDS)
-@pytest.mark.parametrize("k,logn,pbs,g", [(1, 10, (7, 3), 1), (2, 11, (8, 4), 2), (2, 9, (4, 6), 1), (1, 9, (16, 2), 1)])
+@pytest.mark.parametrize("k,logn,pbs,g", [(1, 10, (7, 3), 1), (2, 11, (8, 4), 2), (2, 11, (8, 4), 4), (2, 9, (4, 6), 1), (1, 9, (16, 2), 1)])
 def test_external_product_worst_case_magnitudes(emu, oracle, field, k, logn, pbs, g):
     """Adversarial inputs that drive the integer convolution to its bound: every digit at +B or
     -B/2 and every key word at 0x7FFF8000-type extremes (both 16-bit halves maximal), aligned so
@@ -269,7 +270,7 @@ def test_wide_base_needs_split_goldilocks(emu, oracle):
 
 # ---------------------------------------------------------------- encryption side
 @pytest.mark.parametrize("field", FIELDS)
-@pytest.mark.parametrize("k,logn,g", [(1, 9, 1), (2, 9, 1), (1, 10, 1), (2, 11, 1), (2, 11, 2)])
+@pytest.mark.parametrize("k,logn,g", [(1, 9, 1), (2, 9, 1), (1, 10, 1), (2, 11, 1), (2, 11, 2), (2, 11, 4)])
 def test_glwe_mask_dot_key_vs_oracle(emu, oracle, field, k, logn, g):
     """glwe_mask_dot_key (the a*s of glwe.rs:197/:252) against the oracle's encrypt_glwe_zero /
     decrypt_glwe_ciphertext with the same pre-drawn samples; includes the all-ones key and

@@ -128,3 +128,38 @@ def test_gate_graphs_with_not_mux_and_lut_gates(oracle, log_p, builder):
         assert got[sel] == ((1 - got[out_wires[0]]) if got[out_wires[-1]] else got[out_wires[0]])
         if log_p >= 3:
             assert got[sel3] == got[sel]
+
+
+def test_gate_graph_captured_into_one_hip_graph(oracle):
+    """gates.GraphedCircuit: a whole adder + NOT/MUX evaluation (several truth tables per level,
+    so the context's per-table test-vector cache is exercised) replayed as ONE HIP graph on two
+    different input sets; bit-exact with the eager evaluation and correct after decryption."""
+    import torch
+    p = oracle.Params(2, 9, 16, oracle.Decomposer(4, 6))
+    rng = oracle.Rng(600613)
+    lwe_sk, glwe_sk, bsk, ksk = oracle.keygen(p, rng)
+    m = pkg()
+    gates = importlib.import_module("tfhe_research_amd.gates")
+    circuit, out_wires = gates.ripple_carry_adder(3)
+    inv = circuit.not_(out_wires[0])
+    sel = circuit.mux(out_wires[-1], inv, out_wires[0])
+    inst = 8
+    nprng = np.random.default_rng(5)
+    with m.Context(to_pkg_params(p)) as ctx:
+        ctx.load_bootstrapping_key(bsk, ksk)
+        gc = gates.GraphedCircuit(ctx, circuit, inst, torch.device("cuda:0"))
+        for trial in range(2):
+            a, b = nprng.integers(0, 8, size=inst), nprng.integers(0, 8, size=inst)
+            bits = np.array([[(a[i] >> j) & 1 for j in range(3)] + [(b[i] >> j) & 1 for j in range(3)] for i in range(inst)])
+            cts = np.stack([np.stack([oracle.encrypt_lwe(p, lwe_sk, int(bit), rng) for bit in row]) for row in bits])
+            d_in = torch.from_numpy(cts.view(np.int32)).to("cuda:0")
+            graphed = gc(d_in).cpu().numpy().view(np.uint32).copy()
+            with torch.cuda.stream(gc.stream):
+                eager = gates.evaluate(ctx, circuit, d_in)
+                gc.stream.synchronize()
+            assert np.array_equal(graphed, eager.cpu().numpy().view(np.uint32))
+            for i in range(inst):
+                got = [oracle.decrypt_lwe_message(p, lwe_sk, graphed[i, w]) for w in range(circuit.n_wires)]
+                assert got == circuit.evaluate_clear(bits[i].tolist()), (trial, i)
+                assert sum(got[w] << j for j, w in enumerate(out_wires)) == a[i] + b[i]
+        ctx.set_stream(None)

@@ -49,8 +49,15 @@ struct tfhe_context {
   u32* d_glwe_b = nullptr;
   u32* d_glwe_c = nullptr;
   u32* d_tv = nullptr;        // [batch][N] (or [1][N])
-  u32* d_tv_gate = nullptr;   // [N] test vector of gate calls
-  std::vector<u32> gate_truth;  // truth table (2^inputs entries) whose test vector d_tv_gate holds
+  // test vectors of gate calls, one [N] device buffer per truth table seen (a gate graph alternates
+  // between a handful of tables; re-uploading on every switch would synchronise the stream)
+  struct GateTv {
+    std::vector<u32> truth;  // 2^inputs entries
+    u32* d_tv = nullptr;
+    unsigned long long last_use = 0;
+  };
+  std::vector<GateTv> gate_tvs;
+  unsigned long long gate_clock = 0;
   // generic scratch for the small entry points
   void* d_misc = nullptr;
   size_t misc_bytes = 0;
@@ -356,8 +363,6 @@ int tfhe_context_create_with_backend(const tfhe_params* params, int device, int 
     if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e, "hipEventCreate");
   e = field == launch::kFieldFp64 ? upload_twiddles<FpField>(ctx) : upload_twiddles<GlField>(ctx);  // both Goldilocks fields share the table
   if (e != hipSuccess) return bail(e, "twiddle upload");
-  if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->d_tv_gate), ctx->N * sizeof(u32))) != hipSuccess)
-    return bail(e, "hipMalloc gate tv");
   *out = ctx;
   return TFHE_OK;
 }
@@ -384,10 +389,12 @@ void tfhe_context_destroy(tfhe_context* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   void* ptrs[] = {ctx->d_tw,     ctx->d_bsk,    ctx->d_ksk,    ctx->d_lwe_in, ctx->d_lwe_in2,
                   ctx->d_lwe_big, ctx->d_lwe_out, ctx->d_lwe_ks, ctx->d_glwe_a, ctx->d_glwe_b, ctx->d_glwe_c,
-                  ctx->d_tv,     ctx->d_tv_gate, ctx->d_misc,   ctx->d_ggsw_tmp, ctx->d_ggsw_raw,
+                  ctx->d_tv,     ctx->d_misc,   ctx->d_ggsw_tmp, ctx->d_ggsw_raw,
                   ctx->d_key_tmp};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  for (auto& g : ctx->gate_tvs)
+    if (g.d_tv) (void)hipFree(g.d_tv);
   for (auto& ev : ctx->ev)
     if (ev) (void)hipEventDestroy(ev);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1101,25 +1108,41 @@ static int lut_gate_device(tfhe_context* ctx, const u32* truth, u32 inputs, cons
   if ((st = reserve(ctx, batch))) return st;
   const size_t words = batch * io_words(ctx);
   const u32 entries = 1u << inputs;
-  if (ctx->gate_truth.size() != entries || std::memcmp(ctx->gate_truth.data(), truth, entries * sizeof(u32)) != 0) {
+  tfhe_context::GateTv* slot = nullptr;
+  for (auto& g : ctx->gate_tvs)
+    if (g.truth.size() == entries && std::memcmp(g.truth.data(), truth, entries * sizeof(u32)) == 0) slot = &g;
+  if (!slot) {
     // first use of this truth table: build its test vector on the host and upload it (this one
-    // call synchronises; repeated calls with the same gate do not)
+    // call synchronises; later calls with a table already seen do not).  At most kMaxGateTvs
+    // tables are kept; the least recently used one is replaced.
+    constexpr size_t kMaxGateTvs = 64;
     const u32 pm = 1u << ctx->params.log_p;
     std::vector<u32> lut(pm), tv(ctx->N);
     for (u32 x = 0; x < pm; ++x) lut[x] = truth[x & (entries - 1)];  // test_vector.rs:16 for m = 2
     if ((st = test_from_lut(&ctx->params, lut.data(), pm, tv.data())))
-      return fail(ctx, st, "truth table entries must be < 2^log_p (test_vector.rs:41)");
+      return fail(ctx, st, "truth table / plaintext space mismatch");
     if ((st = check_tv_host(ctx, tv.data(), ctx->N))) return st;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx, hipMemcpy(ctx->d_tv_gate, tv.data(), ctx->N * sizeof(u32), hipMemcpyHostToDevice));
-    ctx->gate_truth.assign(truth, truth + entries);
+    if (ctx->gate_tvs.size() < kMaxGateTvs) {
+      ctx->gate_tvs.emplace_back();
+      slot = &ctx->gate_tvs.back();
+      HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&slot->d_tv), ctx->N * sizeof(u32)));
+    } else {
+      slot = &ctx->gate_tvs[0];
+      for (auto& g : ctx->gate_tvs)
+        if (g.last_use < slot->last_use) slot = &g;
+    }
+    slot->truth.clear();  // not a valid entry until the upload has succeeded
+    HIP_TRY(ctx, hipMemcpy(slot->d_tv, tv.data(), ctx->N * sizeof(u32), hipMemcpyHostToDevice));
+    slot->truth.assign(truth, truth + entries);
   }
+  slot->last_use = ++ctx->gate_clock;
   const u32* d_in = cts[0];
   for (u32 i = 1; i < inputs; ++i) {  // 2*ct1 + ct0 (boolean.rs:18), then + 4*ct2, ...
     HIP_TRY(ctx, launch::lwe_linear(ctx->stream, 1u, d_in, 1u << i, cts[i], words, ctx->d_lwe_in2));
     d_in = ctx->d_lwe_in2;
   }
-  return enqueue_bootstrap(ctx, d_in, batch, ctx->d_tv_gate, 1, ctx->d_lwe_big, lwe_out);
+  return enqueue_bootstrap(ctx, d_in, batch, slot->d_tv, 1, ctx->d_lwe_big, lwe_out);
 }
 
 int tfhe_gate_batch_device(tfhe_context* ctx, const uint32_t truth[4], const uint32_t* ct0,

@@ -8,10 +8,18 @@
 namespace tfhe {
 namespace {
 
-// waves per polynomial: one, except N = 2048 where a lane would otherwise hold 32 elements per array
+// waves per polynomial: one, except N = 2048, where four waves hold 8 elements per array each.
+// (With two waves -- 16 elements, 256 VGPRs -- a k = 2 team is 6 waves on a CU that then has room
+// for 8: SIMDs end up with 2, 2, 1, 1 waves and the team runs at the pace of the shared ones.  Four
+// waves per polynomial fit 170 VGPRs, so the 12-wave team sits 3, 3, 3, 3.)
+#ifndef TFHE_GROUP_N2048
+#define TFHE_GROUP_N2048 4
+#endif
+// (N = 1024 over two waves was measured too: 97.9 ms against 64.0 ms per cfg2 batch -- a fourth
+// register pass and cross-wave barriers cost more than the third wave per SIMD gives.)
 template <int LOGN>
 struct GroupOf {
-  static constexpr int value = (LOGN >= 11) ? 2 : 1;
+  static constexpr int value = (LOGN >= 11) ? TFHE_GROUP_N2048 : 1;
 };
 
 template <class Elem, int G>
@@ -31,12 +39,16 @@ struct DeviceWave {
   // the same transforms, hence the same number of barriers).
   __device__ __forceinline__ void poly_sync() const {
     if (G == 1) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      wave_sync();
     } else {
       __syncthreads();
     }
+  }
+  // Orders the LDS stores of this wave's lanes before their later LDS loads (wave-local exchanges)
+  __device__ __forceinline__ void wave_sync() const {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
   // workgroup barrier: the team of K+1 groups that shares one sample IS the workgroup
   // (timing experiment: compiling the barriers out changes cfg2 by -1 % and makes cfg3 20 % SLOWER --
@@ -72,8 +84,8 @@ struct TeamCfg {
   static constexpr unsigned kGroupLds = (unsigned)N * 8u + (unsigned)N * 4u;
   static constexpr size_t kTwBytes = (size_t)ntt_twiddle_words(N) * 8;  // multiple of 16
   static constexpr size_t kLds = kTwBytes + (size_t)(K + 1) * kGroupLds;
-  static constexpr int kMinWavesGl = TFHE_WAVES_PER_SIMD_GL;
-  static constexpr int kMinWavesFp = TFHE_WAVES_PER_SIMD_FP;
+  static constexpr int kMinWavesGl = (NttShape<LOGN, G>::kE == 8) ? 3 : TFHE_WAVES_PER_SIMD_GL;
+  static constexpr int kMinWavesFp = (NttShape<LOGN, G>::kE == 8) ? 3 : TFHE_WAVES_PER_SIMD_FP;
 };
 
 template <class F, int LOGN, int K>
@@ -197,8 +209,12 @@ external_product_kernel(PbsParams P, const typename F::elem* __restrict__ tw,
 
 // ------------------------------------------------------------------------------ key switch
 // out[b][c] = -sum_{i<big_n, l<levels} digit_l(lwe[b][i]) * ksk[i*levels + l][c];  out[b][n] += b
-// Tiled as a wrapping-u32 GEMM: a workgroup owns kKsSamples samples x 64 output columns and walks
-// the big_n*levels key rows in chunks; digits of the chunk are produced once into LDS.
+// Tiled as a wrapping-u32 GEMM: a workgroup owns kKsSamples samples x 128 output columns and walks
+// key rows in chunks; digits of the chunk are produced once into LDS.  Small batches do not give
+// enough (sample, column) tiles to fill 256 CUs, so the big_n mask words are also split over
+// gridDim.z: with more than one split the partial sums go to the (pre-zeroed) output with u32
+// atomic adds -- wrapping addition is associative and commutative, the bits do not depend on the
+// order.
 constexpr int kKsSamples = 32;     // samples per workgroup
 constexpr int kKsColsPerLane = 2;  // output columns per lane
 constexpr int kKsCols = 64 * kKsColsPerLane;  // output columns per workgroup
@@ -208,7 +224,7 @@ constexpr int kKsPerThread = 8;    // samples per thread (kKsSamples / 4 waves)
 __global__ void __launch_bounds__(256) key_switch_kernel(KsParams Kp, u32 big_n, u32 n,
                                                          const u32* __restrict__ lwe_in, size_t batch,
                                                          const u32* __restrict__ ksk,
-                                                         u32* __restrict__ lwe_out) {
+                                                         u32* __restrict__ lwe_out, u32 words_per_split) {
   u32* dig = reinterpret_cast<u32*>(g_smem);  // [kKsWords*levels][kKsSamples]
   const int tx = (int)(threadIdx.x & 63u);
   const int ty = (int)(threadIdx.x >> 6);
@@ -230,7 +246,9 @@ __global__ void __launch_bounds__(256) key_switch_kernel(KsParams Kp, u32 big_n,
 #pragma unroll
     for (int s = 0; s < kKsPerThread; ++s) acc[c][s] = 0;
 
-  for (u32 w0 = 0; w0 < big_n; w0 += kKsWords) {
+  const u32 w_begin = blockIdx.z * words_per_split;  // multiple of kKsWords
+  const u32 w_end = (w_begin + words_per_split < big_n) ? w_begin + words_per_split : big_n;
+  for (u32 w0 = w_begin; w0 < w_end; w0 += kKsWords) {
     // 256 threads decompose 32 samples x 8 words: thread -> (sample = tid / 8, word = tid % 8)
     {
       const int sl = (int)(threadIdx.x >> 3);
@@ -238,7 +256,7 @@ __global__ void __launch_bounds__(256) key_switch_kernel(KsParams Kp, u32 big_n,
       const size_t sample = s0 + sl;
       const u32 word = w0 + wl;
       u32 v = 0;
-      if (sample < batch && word < big_n) v = lwe_in[sample * ((size_t)big_n + 1) + word];
+      if (sample < batch && word < w_end) v = lwe_in[sample * ((size_t)big_n + 1) + word];
       v = round_value(v, Kp.ignored_bits);
       u32 carry = 0;
       for (u32 t = 0; t < levels; ++t) {  // LSB -> MSB, level index counts from the MSB
@@ -247,7 +265,7 @@ __global__ void __launch_bounds__(256) key_switch_kernel(KsParams Kp, u32 big_n,
       }
     }
     __syncthreads();
-    const u32 rows = ((big_n - w0 < (u32)kKsWords) ? (big_n - w0) : (u32)kKsWords) * levels;
+    const u32 rows = ((w_end - w0 < (u32)kKsWords) ? (w_end - w0) : (u32)kKsWords) * levels;
     const u32* krow = ksk + (size_t)w0 * levels * width;
 #pragma unroll 4
     for (u32 r = 0; r < rows; ++r) {
@@ -273,8 +291,9 @@ __global__ void __launch_bounds__(256) key_switch_kernel(KsParams Kp, u32 big_n,
       const size_t sample = s0 + ty * kKsPerThread + s;
       if (sample >= batch) continue;
       u32 v = 0u - (u32)acc[c][s];
-      if (col[c] == n) v += lwe_in[sample * ((size_t)big_n + 1) + big_n];
-      lwe_out[sample * width + col[c]] = v;
+      if (col[c] == n && blockIdx.z == 0) v += lwe_in[sample * ((size_t)big_n + 1) + big_n];
+      if (gridDim.z == 1) lwe_out[sample * width + col[c]] = v;
+      else atomicAdd(&lwe_out[sample * width + col[c]], v);
     }
   }
 }
@@ -644,8 +663,21 @@ hipError_t key_switch(hipStream_t s, const KsParams& K, u32 big_n, u32 n, const 
   const size_t lds = (size_t)kKsWords * K.levels * kKsSamples * sizeof(u32);
   if (lds > 64 * 1024) return hipErrorInvalidValue;
   dim3 grid((n + 1 + kKsCols - 1) / kKsCols, (unsigned)((batch + kKsSamples - 1) / kKsSamples));
+  // aim at >= 4 workgroups per CU; a split covers a multiple of kKsWords words, at least 64
+  unsigned splits = 1024u / (grid.x * grid.y);
+  const unsigned max_splits = (big_n + 63u) / 64u;
+  if (splits > max_splits) splits = max_splits;
+  if (splits > 32u) splits = 32u;
+  if (splits < 1u) splits = 1u;
+  u32 words_per_split = ((big_n + splits - 1) / splits + kKsWords - 1) / kKsWords * kKsWords;
+  splits = (big_n + words_per_split - 1) / words_per_split;
+  grid.z = splits;
+  if (splits > 1) {
+    hipError_t e = hipMemsetAsync(lwe_out, 0, batch * ((size_t)n + 1) * sizeof(u32), s);
+    if (e != hipSuccess) return e;
+  }
   hipLaunchKernelGGL(key_switch_kernel, grid, dim3(256), lds, s, K, big_n, n, lwe_in, batch, ksk,
-                     lwe_out);
+                     lwe_out, words_per_split);
   return hipGetLastError();
 }
 

@@ -171,10 +171,11 @@ TFHE_HD void external_product_team(const Ctx& c, const PbsParams& P, const typen
       // digits are tiny (|d| <= B <= 2^F::kSmallBits, enforced when the context picks the field):
       // the first butterfly stage uses F::mul_small
       ntt_forward<F, LOGN, G, true>(c, work);
-      // publish: element r of thread tid at [r*T + tid] (conflict-free 8-byte accesses)
+      // publish: element r of thread tid at exchange_slot(tid, r) -- inside my wave's own part of
+      // the buffer (wave_ntt.h), conflict-free 8-byte accesses
       elem* mine = c.scratch();
 #pragma unroll
-      for (int r = 0; r < E; ++r) mine[r * T + lane] = work[r];
+      for (int r = 0; r < E; ++r) mine[exchange_slot<LOGN, G>(lane, r)] = work[r];
     }
     c.team_sync();
     static_for<0, CHUNKS>([&](auto ci_c) {
@@ -191,7 +192,7 @@ TFHE_HD void external_product_team(const Ctx& c, const PbsParams& P, const typen
       const elem* spec = c.scratch_of(s);
       elem d[CH];
 #pragma unroll
-      for (int r = 0; r < CH; ++r) d[r] = spec[(r0 + r) * T + lane];
+      for (int r = 0; r < CH; ++r) d[r] = spec[exchange_slot<LOGN, G>(lane, r0 + r)];
       c.compiler_fence();  // keep the next chunk's loads above this chunk's arithmetic
 #pragma unroll
       for (int r = 0; r < CH; ++r)

@@ -1,11 +1,11 @@
 // wave_ntt.h -- exact negacyclic NTT of one polynomial held by a GROUP of G 64-lane wavefronts
-// (G = 1: one wave per polynomial, no barrier inside a transform; G = 2 for N = 2048 so that a lane
-// still holds only 16 elements per array).
+// (G = 1: one wave per polynomial, no barrier inside a transform; G = 4 for N = 2048 so that a lane
+// holds only 8 elements per array and three waves fit a SIMD; G = 2 is kept and tested as well).
 //
 // N = 2^LOGN coefficients live in E = N/(64 G) registers per lane (8 bytes each); below "tid" is the
 // thread index inside the group (0 .. 64G-1) and TB = log2(64 G).  The transform is the
 // merged-psi Cooley-Tukey NTT (natural order in, bit-reversed order out) and its Gentleman-Sande
-// inverse, executed as three "register passes".  A pass owns a window of e = log2(E) index bits:
+// inverse, executed as three "register passes" (four when e = 3 does not cover TB = 8 bits twice).  A pass owns a window of e = log2(E) index bits:
 // in window [LO, LO+e) a lane holds the E indices that differ only in those bits,
 //     j = (hi << (LO+e)) | (r << LO) | lo,   lane = (hi << LO) | lo,   r = register number,
 // so every butterfly of the stages on those bits is lane-local.  Between passes the polynomial
@@ -15,8 +15,9 @@
 //
 //   forward : window [TB,TB+e) (j = r*64G + tid, coalesced) -> [TB-e,TB) -> [0,e)
 //   inverse : the mirror image, ends in [TB,TB+e) again.
-// (in the formulas above read "lane" as tid and 6 as TB.)  For G > 1 the transposes cross waves, so
-// Ctx::poly_sync() is a workgroup barrier there; for G = 1 it only fences the compiler.
+// (in the formulas above read "lane" as tid and 6 as TB.)  For G > 1 the transpose next to window
+// [TB,TB+e) crosses waves and uses Ctx::poly_sync() (a workgroup barrier); the other one stays
+// inside each wave's own part of the buffer and only needs Ctx::wave_sync() (see ntt_transpose).
 //
 // In window [0,e) position pos = tid*E + r of the bit-reversed-order spectrum sits in register r.
 // The inverse is NOT scaled by N^-1: the bootstrapping key is pre-scaled instead (bsk_prepare).
@@ -30,7 +31,8 @@
 // fp64); elements are 8 bytes in both, so layouts, swizzles and LDS budgets are identical.
 //
 // Ctx (GPU: DeviceWave in kernels.hip; CPU tests: the SIMT emulator in tests/emu) provides
-//   int lane() const;  void sync() const;  elem* scratch() const;  const elem* twiddles() const;
+//   int tid() const;  void poly_sync() const;  void wave_sync() const;  elem* scratch() const;
+//   const elem* twiddles() const;
 #pragma once
 #include "field_fp.h"
 #include "field_gl.h"
@@ -51,11 +53,15 @@ struct NttShape {
   static constexpr int kEBits = LOGN - kTBits;
   static constexpr int kE = 1 << kEBits;
   static_assert(kEBits >= 3 && kEBits <= 5, "8..32 elements per lane");
-  static_assert(kTBits <= 2 * kEBits, "three register passes must cover all index bits");
-  // window lows of the three passes (forward order)
+  // three register passes cover 3e index bits; a fourth one (N = 2048 over 4 waves: e = 3) takes
+  // the remaining low bits
+  static constexpr int kPasses = (kTBits <= 2 * kEBits) ? 3 : 4;
+  static_assert(kTBits <= 3 * kEBits, "four register passes must cover all index bits");
+  // window lows of the passes (forward order); kLo4 is only used when kPasses == 4
   static constexpr int kLo1 = kTBits;
   static constexpr int kLo2 = kTBits - kEBits;
-  static constexpr int kLo3 = 0;
+  static constexpr int kLo3 = (kPasses == 3) ? 0 : kTBits - 2 * kEBits;
+  static constexpr int kLo4 = 0;
 };
 
 // XOR swizzle of the transpose buffer (element = 8 bytes).  Each one makes every ds_write_b64 and
@@ -66,6 +72,11 @@ TFHE_HD int ntt_swizzle(int j) {
   if (G == 1 && LOGN == 9) return j ^ ((j >> 3) & 7) ^ (((j >> 6) & 3) << 3);
   if (G == 1 && LOGN == 11) return j ^ ((j >> 5) & 31);
   if (G == 2 && LOGN == 11) return j ^ ((j >> 1) & 7) ^ ((j >> 4) & 31);
+  if (G == 4 && LOGN == 11) {
+    // found by search over triangular XOR maps (tools/ntt_model.py::conflicts_grouped(11, 4))
+    const int b4 = (j >> 4) & 1, b5 = (j >> 5) & 1, b6 = (j >> 6) & 1, b7 = (j >> 7) & 1;
+    return j ^ b5 ^ ((b5 ^ b4) << 1) ^ ((b6 ^ b5) << 2) ^ ((b7 ^ b5 ^ b4) << 3) ^ (b7 << 4);
+  }
   return j;  // correct for any shape, just not conflict-free
 }
 
@@ -84,17 +95,43 @@ TFHE_HD int spectrum_slot(int tid, int r) {
   return (r >> 1) * (2 * NttShape<LOGN, G>::kThreads) + tid * 2 + (r & 1);
 }
 
+// position of spectrum register r of thread `tid` in the group's LDS buffer when a transformed
+// polynomial is handed to the other groups of the team: wave w of the group writes only inside
+// [w*N/G, (w+1)*N/G), the same region its wave-local transposes use (see ntt_transpose), 64
+// consecutive 8-byte words per register (conflict-free)
+template <int LOGN, int G>
+TFHE_HD int exchange_slot(int tid, int r) {
+  return (tid >> 6) * (NttShape<LOGN, G>::kN / G) + r * 64 + (tid & 63);
+}
+
+// Transpose between two register windows through the group's LDS buffer.
+// In a window with LO <= 6 a lane of wave w (= tid >> 6) holds only indices whose top log2(G) bits
+// equal w, and the swizzles only permute low address bits, so its accesses stay inside the wave's
+// own N/G-element region of the buffer; in the top window (LO = TB > 6) a lane touches every region.
+//   both windows low : wave-local exchange, no workgroup barrier.
+//   FROM is the top window (forward direction): the writes land in other waves' regions, so a
+//     barrier first lets every wave finish reading its own region, a second one separates the
+//     writes from the (own-region) reads.
+//   TO is the top window (inverse direction): own-region writes, barrier, reads from every region,
+//     and a barrier after them before anybody writes again.
+// Invariant every user of the buffer keeps: reads that leave the own region (here, and the team's
+// spectrum exchange in pbs_wave.h) are followed by a workgroup barrier before the next write.
+// G == 1: everything is wave-local.
 template <class F, int LOGN, int G, int LO_FROM, int LO_TO, class Ctx>
 TFHE_HD void ntt_transpose(const Ctx& c, typename F::elem (&x)[NttShape<LOGN, G>::kE]) {
   constexpr int E = NttShape<LOGN, G>::kE;
+  constexpr bool WRITES_CROSS = G > 1 && LO_FROM > 6;
+  constexpr bool READS_CROSS = G > 1 && LO_TO > 6;
+  static_assert(!(WRITES_CROSS && READS_CROSS), "one of the two windows is a low one");
   typename F::elem* buf = c.scratch();
   const int tid = c.tid();
+  if (WRITES_CROSS) c.poly_sync();
 #pragma unroll
   for (int r = 0; r < E; ++r) buf[ntt_swizzle<LOGN, G>(ntt_index<LOGN, G, LO_FROM>(tid, r))] = x[r];
-  c.poly_sync();
+  if (WRITES_CROSS || READS_CROSS) c.poly_sync(); else c.wave_sync();
 #pragma unroll
   for (int r = 0; r < E; ++r) x[r] = buf[ntt_swizzle<LOGN, G>(ntt_index<LOGN, G, LO_TO>(tid, r))];
-  c.poly_sync();
+  if (READS_CROSS) c.poly_sync(); else c.wave_sync();
 }
 
 // forward stages on bits BHI..BLO (descending) of window [LO, LO+e).  SMALL_FIRST: the inputs of
@@ -174,14 +211,22 @@ TFHE_HD void ntt_forward(const Ctx& c, typename F::elem (&x)[NttShape<LOGN, G>::
   ntt_transpose<F, LOGN, G, S::kLo1, S::kLo2>(c, x);
   ntt_pass_forward<F, LOGN, G, S::kLo2, S::kTBits - 1, S::kLo2, false>(c, x);
   ntt_transpose<F, LOGN, G, S::kLo2, S::kLo3>(c, x);
-  ntt_pass_forward<F, LOGN, G, S::kLo3, S::kLo2 - 1, 0, false>(c, x);
+  ntt_pass_forward<F, LOGN, G, S::kLo3, S::kLo2 - 1, S::kLo3, false>(c, x);
+  if constexpr (S::kPasses == 4) {
+    ntt_transpose<F, LOGN, G, S::kLo3, S::kLo4>(c, x);
+    ntt_pass_forward<F, LOGN, G, S::kLo4, S::kLo3 - 1, 0, false>(c, x);
+  }
 }
 
 // in: x[r] = A_bitrev[tid*E + r].  out: x[r] = N * a[r*64G + tid] (unscaled inverse).
 template <class F, int LOGN, int G, class Ctx>
 TFHE_HD void ntt_inverse(const Ctx& c, typename F::elem (&x)[NttShape<LOGN, G>::kE]) {
   using S = NttShape<LOGN, G>;
-  ntt_pass_inverse<F, LOGN, G, S::kLo3, S::kLo2 - 1, 0>(c, x);
+  if constexpr (S::kPasses == 4) {
+    ntt_pass_inverse<F, LOGN, G, S::kLo4, S::kLo3 - 1, 0>(c, x);
+    ntt_transpose<F, LOGN, G, S::kLo4, S::kLo3>(c, x);
+  }
+  ntt_pass_inverse<F, LOGN, G, S::kLo3, S::kLo2 - 1, S::kLo3>(c, x);
   ntt_transpose<F, LOGN, G, S::kLo3, S::kLo2>(c, x);
   ntt_pass_inverse<F, LOGN, G, S::kLo2, S::kTBits - 1, S::kLo2>(c, x);
   ntt_transpose<F, LOGN, G, S::kLo2, S::kLo1>(c, x);

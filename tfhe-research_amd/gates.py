@@ -135,22 +135,20 @@ def full_adder_lut3(width: int) -> Tuple[Circuit, List[int]]:
     return c, out
 
 
-def evaluate(ctx, circuit: Circuit, inputs):
-    """inputs: device tensor [instances][n_inputs][n+1] (32-bit) of LWE encryptions of bits, one row
-    of wires per independent instance of the circuit.  Returns [instances][n_wires][n+1] on the
-    same device.  All instances advance level by level; per level and truth table one batched gate
-    call covers instances x gates ciphertexts."""
+@dataclass
+class _Step:
+    kind: str
+    truth: Optional[Tuple[int, ...]]
+    operands: list          # device index tensors, one per operand position (as listed in the gate)
+    dst: object             # device index tensor of the output wires
+    count: int
+
+
+def plan(circuit: Circuit, device) -> List[_Step]:
+    """Index tensors of every (level, gate kind) group, built once: evaluation itself then issues
+    no host-to-device copies and can be captured into a HIP graph."""
     import torch
-    inst, n_in, width = inputs.shape
-    assert n_in == circuit.n_inputs and width == ctx.io_dim + 1
-    dev = inputs.device
-    wires = torch.empty((inst, circuit.n_wires, width), dtype=inputs.dtype, device=dev)
-    wires[:, :n_in] = inputs
-
-    def operand(gs, pos):
-        idx = torch.tensor([circuit.gates[g][pos] for g in gs], device=dev)
-        return wires.index_select(1, idx).reshape(-1, width).contiguous()
-
+    steps: List[_Step] = []
     for level in circuit.levels():
         groups: Dict[Tuple, List[int]] = {}
         for g in level:
@@ -158,19 +156,82 @@ def evaluate(ctx, circuit: Circuit, inputs):
             key = (kind, len(circuit.gates[g]) - 1, circuit.luts.get(g))
             groups.setdefault(key, []).append(g)
         for (kind, arity, truth), gs in groups.items():
-            dst = torch.tensor([circuit.n_inputs + g for g in gs], device=dev)
-            if kind == "not":
-                out = ctx.lwe_not(operand(gs, 1))
-            elif kind == "mux":
-                sel, a, b = operand(gs, 1), operand(gs, 2), operand(gs, 3)
-                t1 = ctx.gate(TRUTH["and"], a, sel)
-                t2 = ctx.gate(_ANDNOT, b, sel)
-                out = ctx.lwe_linear(1, t1, 1, t2)
-            elif kind == "lut":
-                # operands are listed most significant first; the ABI takes cts[0] = least significant
-                cts = [operand(gs, pos) for pos in range(arity, 0, -1)]
-                out = ctx.lut_gate(truth, cts)
-            else:
-                out = ctx.gate(TRUTH[kind], operand(gs, 2), operand(gs, 1))
-            wires[:, dst] = out.reshape(inst, len(gs), width)
+            ops = [torch.tensor([circuit.gates[g][pos] for g in gs], device=device) for pos in range(1, arity + 1)]
+            dst = torch.tensor([circuit.n_inputs + g for g in gs], device=device)
+            steps.append(_Step(kind, truth, ops, dst, len(gs)))
+    return steps
+
+
+def _run(ctx, steps: List[_Step], wires):
+    inst, _, width = wires.shape
+
+    def operand(step, pos):
+        return wires.index_select(1, step.operands[pos]).reshape(-1, width).contiguous()
+
+    for st in steps:
+        if st.kind == "not":
+            out = ctx.lwe_not(operand(st, 0))
+        elif st.kind == "mux":
+            sel, a, b = operand(st, 0), operand(st, 1), operand(st, 2)
+            t1 = ctx.gate(TRUTH["and"], a, sel)
+            t2 = ctx.gate(_ANDNOT, b, sel)
+            out = ctx.lwe_linear(1, t1, 1, t2)
+        elif st.kind == "lut":
+            # operands are listed most significant first; the ABI takes cts[0] = least significant
+            out = ctx.lut_gate(st.truth, [operand(st, pos) for pos in range(len(st.operands) - 1, -1, -1)])
+        else:
+            out = ctx.gate(TRUTH[st.kind], operand(st, 1), operand(st, 0))
+        wires[:, st.dst] = out.reshape(inst, st.count, width)
     return wires
+
+
+def evaluate(ctx, circuit: Circuit, inputs, steps: Optional[List[_Step]] = None):
+    """inputs: device tensor [instances][n_inputs][words] (32-bit) of LWE encryptions of bits, one
+    row of wires per independent instance of the circuit (words = ctx.io_dim + 1).  Returns
+    [instances][n_wires][words] on the same device.  All instances advance level by level; per level
+    and truth table one batched gate call covers instances x gates ciphertexts."""
+    import torch
+    inst, n_in, width = inputs.shape
+    assert n_in == circuit.n_inputs and width == ctx.io_dim + 1
+    wires = torch.empty((inst, circuit.n_wires, width), dtype=inputs.dtype, device=inputs.device)
+    wires[:, :n_in] = inputs
+    return _run(ctx, steps if steps is not None else plan(circuit, inputs.device), wires)
+
+
+class GraphedCircuit:
+    """A circuit for a fixed number of instances captured into ONE HIP graph: after the first call
+    a whole evaluation -- every gather, linear combination, blind rotation, key switch and
+    scatter of every level -- is a single graph launch.
+
+        gc = GraphedCircuit(ctx, circuit, instances, device)
+        wires = gc(inputs)        # [instances][n_wires][words]; the buffer is reused by the next call
+    """
+
+    def __init__(self, ctx, circuit: Circuit, instances: int, device, dtype=None):
+        import torch
+        self.ctx, self.circuit = ctx, circuit
+        width = ctx.io_dim + 1
+        dtype = dtype or torch.int32
+        self.inputs = torch.zeros((instances, circuit.n_inputs, width), dtype=dtype, device=device)
+        self.wires = torch.empty((instances, circuit.n_wires, width), dtype=dtype, device=device)
+        self.steps = plan(circuit, device)
+        self.stream = torch.cuda.Stream(device=device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(self.stream):
+            ctx.use_torch_stream()
+            # eager warm-up: sizes the context's workspace, uploads every truth table's test vector
+            # and sets the kernels' one-time attributes -- none of which may happen while capturing
+            self.wires[:, :circuit.n_inputs] = self.inputs
+            _run(ctx, self.steps, self.wires)
+            self.stream.synchronize()
+            with torch.cuda.graph(self.graph, stream=self.stream):
+                self.wires[:, :circuit.n_inputs] = self.inputs
+                _run(ctx, self.steps, self.wires)
+
+    def __call__(self, inputs):
+        import torch
+        with torch.cuda.stream(self.stream):
+            self.inputs.copy_(inputs, non_blocking=True)
+            self.graph.replay()
+        self.stream.synchronize()
+        return self.wires

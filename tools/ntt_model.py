@@ -237,21 +237,30 @@ def selfcheck(logn, seed=1):
 
 def conflicts_grouped(logn=11, g=2):
     """Same bank-conflict evaluation for G waves per polynomial (tid has 6 + log2(g) bits); the
-    swizzle is the one in wave_ntt.h::ntt_swizzle<11, 2>."""
+    swizzles are the ones in wave_ntt.h::ntt_swizzle<11, 2> and <11, 4>.  Returns, per transpose
+    (write window low, read window low), the worst (write, read) serialisation factor: 1 = none."""
     tb = 6 + (g.bit_length() - 1)
     e = logn - tb
     E = 1 << e
 
     def swz(j):
-        return j ^ ((j >> 1) & 7) ^ ((j >> 4) & 31)
+        if g == 2:
+            return j ^ ((j >> 1) & 7) ^ ((j >> 4) & 31)
+        b4, b5, b6, b7 = (j >> 4) & 1, (j >> 5) & 1, (j >> 6) & 1, (j >> 7) & 1
+        return j ^ b5 ^ ((b5 ^ b4) << 1) ^ ((b6 ^ b5) << 2) ^ ((b7 ^ b5 ^ b4) << 3) ^ (b7 << 4)
 
     def index(tid, r, lo):
         return ((tid >> lo) << (lo + e)) | (r << lo) | (tid & ((1 << lo) - 1))
 
     assert sorted(swz(j) for j in range(1 << logn)) == list(range(1 << logn))
-    los = [tb, tb - e, 0]
+    # a wave's accesses in the low windows stay inside its own N/g region (wave-local transposes)
+    for j in range(1 << logn):
+        assert swz(j) >> (logn - (g.bit_length() - 1)) == j >> (logn - (g.bit_length() - 1))
+    los = [tb, tb - e, 0] if tb <= 2 * e else [tb, tb - e, tb - 2 * e, 0]
+    pairs = list(zip(los[:-1], los[1:]))
+    pairs += [(b, a) for a, b in reversed(pairs)]
     out = {}
-    for wlo, rlo in [(los[0], los[1]), (los[1], los[2]), (los[2], los[1]), (los[1], los[0])]:
+    for wlo, rlo in pairs:
         ww = wr = 0
         for wave in range(g):
             for r in range(E):
@@ -277,3 +286,4 @@ if __name__ == "__main__":
     for logn in (9, 10, 11):
         print(logn, selfcheck(logn))
     print("11 x2 waves", conflicts_grouped())
+    print("11 x4 waves", conflicts_grouped(11, 4))
