@@ -19,9 +19,12 @@ using namespace tfhe;
 
 namespace {
 
+int g_exchange_buffers = 1;  // exchange buffers per group (kernels.hip::ExchangeBuffersOf)
+
 template <class Elem>
 struct HostTeam {
   int n, g;  // ring degree, waves per polynomial group
+  int exb, groups;
   std::vector<Elem> scratch, tw;
   std::vector<u32> acc;
   pthread_barrier_t team_bar;
@@ -33,13 +36,20 @@ template <class Elem>
 struct HostWave {
   int lane_, wave_;
   HostTeam<Elem>* t_;
+  int buf_ = 0;  // exchange buffer in use: buffer b of group c is at scratch[(b*groups + c)*n]
+  int exchange_buffers() const { return t_->exb; }
+  HostWave with_exchange_buffer(int i) const {
+    HostWave w = *this;
+    w.buf_ = i;
+    return w;
+  }
   int tid() const { return (wave_ % t_->g) * 64 + lane_; }
   int group() const { return wave_ / t_->g; }
   void poly_sync() const { pthread_barrier_wait(&t_->group_bars[group()]); }
   void wave_sync() const { pthread_barrier_wait(&t_->wave_bars[wave_]); }
   void team_sync() const { pthread_barrier_wait(&t_->team_bar); }
-  Elem* scratch() const { return t_->scratch.data() + (size_t)group() * t_->n; }
-  const Elem* scratch_of(int s) const { return t_->scratch.data() + (size_t)s * t_->n; }
+  Elem* scratch() const { return t_->scratch.data() + ((size_t)buf_ * t_->groups + group()) * t_->n; }
+  const Elem* scratch_of(int s) const { return t_->scratch.data() + ((size_t)buf_ * t_->groups + s) * t_->n; }
   u32* acc() const { return t_->acc.data() + (size_t)group() * t_->n; }
   const Elem* twiddles() const { return t_->tw.data(); }
   u32 uniform(u32 v) const { return v; }
@@ -53,7 +63,9 @@ void run_team(int logn, int groups, int g, const std::function<void(const HostWa
   HostTeam<elem> team;
   team.n = 1 << logn;
   team.g = g;
-  team.scratch.resize((size_t)groups * team.n);
+  team.exb = g_exchange_buffers;
+  team.groups = groups;
+  team.scratch.resize((size_t)groups * team.n * team.exb);
   team.acc.resize((size_t)groups * team.n);
   team.tw.resize(ntt_twiddle_words(team.n));
   F::fill_twiddles(logn, team.tw.data());
@@ -67,7 +79,7 @@ void run_team(int logn, int groups, int g, const std::function<void(const HostWa
   for (int w = 0; w < waves; ++w)
     for (int l = 0; l < kWave; ++l)
       th.emplace_back([&, w, l] {
-        HostWave<elem> ctx{l, w, &team};
+        HostWave<elem> ctx{l, w, &team, 0};
         body(ctx);
       });
   for (auto& t : th) t.join();
@@ -186,6 +198,7 @@ PbsParams make_params(u32 n, u32 k, u32 log_n, u32 log_p, u32 padding, u32 log_b
 extern "C" {
 
 void emu_set_aligned(int aligned) { g_aligned = aligned != 0; }
+void emu_set_exchange_buffers(int n) { g_exchange_buffers = n == 2 ? 2 : 1; }
 int emu_field_parts(int field) { return field == 1 ? 1 : 2; }
 
 int emu_poly_ntt(int field, int logn, int g, const void* in, void* out, int inverse) {

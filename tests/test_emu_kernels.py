@@ -180,9 +180,17 @@ CASES = [
 ]
 
 
+@pytest.fixture(params=[1, 2], ids=["one-exchange-buffer", "two-exchange-buffers"])
+def exchange_buffers(emu, request):
+    """both spectrum-exchange schemes of external_product_team (kernels.hip picks per ring degree)"""
+    emu.emu_set_exchange_buffers(request.param)
+    yield request.param
+    emu.emu_set_exchange_buffers(1)
+
+
 @pytest.mark.parametrize("field", FIELDS)
 @pytest.mark.parametrize("k,logn,n,pbs,log_p,g", CASES)
-def test_external_product_vs_oracle(emu, oracle, field, k, logn, n, pbs, log_p, g):
+def test_external_product_vs_oracle(emu, oracle, exchange_buffers, field, k, logn, n, pbs, log_p, g):
     params = oracle.Params(k, logn, n, oracle.Decomposer(*pbs), log_p=log_p)
     rng = np.random.default_rng(11 * logn + k)
     ggsw = rng.integers(0, 1 << 32, size=(params.R, k + 1, params.N), dtype=np.uint64).astype(np.uint32)
@@ -231,7 +239,7 @@ def test_external_product_worst_case_magnitudes(emu, oracle, field, k, logn, pbs
 
 @pytest.mark.parametrize("field", FIELDS)
 @pytest.mark.parametrize("k,logn,n,pbs,log_p,g", CASES)
-def test_blind_rotate_and_extract_vs_oracle(emu, oracle, field, k, logn, n, pbs, log_p, g):
+def test_blind_rotate_and_extract_vs_oracle(emu, oracle, exchange_buffers, field, k, logn, n, pbs, log_p, g):
     params = oracle.Params(k, logn, n, oracle.Decomposer(*pbs), log_p=log_p)
     batch = 2
     lut = np.random.default_rng(5).integers(0, 1 << log_p, size=1 << log_p)

@@ -22,14 +22,26 @@ struct GroupOf {
   static constexpr int value = (LOGN >= 11) ? TFHE_GROUP_N2048 : 1;
 };
 
-template <class Elem, int G>
+template <class Elem, int G, int EXB = 1>
 struct DeviceWave {
-  unsigned char* team_base_;  // LDS of group 0 of this team
-  Elem* scratch_;
+  unsigned char* team_base_;  // LDS of group 0 of this team (its exchange buffer in use)
+  Elem* scratch_;             // my group's exchange / transpose buffer in use
   u32* acc_;
   const Elem* tw_;
   int group_;                 // polynomial / output column of my group
   unsigned group_stride_;     // bytes of LDS per group
+  unsigned buffer_bytes_;     // bytes of one exchange buffer (EXB of them per group, back to back)
+  // number of exchange buffers per group and a copy of this context that works in buffer i
+  // (pbs_wave.h::external_product_team); buffer 0 is the one selected at construction
+  __device__ __forceinline__ int exchange_buffers() const { return EXB; }
+  __device__ __forceinline__ DeviceWave with_exchange_buffer(int i) const {
+    DeviceWave w = *this;
+    if (EXB > 1) {
+      w.team_base_ += (size_t)i * buffer_bytes_;
+      w.scratch_ = reinterpret_cast<Elem*>(reinterpret_cast<unsigned char*>(scratch_) + (size_t)i * buffer_bytes_);
+    }
+    return w;
+  }
   // thread index inside my polynomial's group of G waves
   __device__ __forceinline__ int tid() const { return (int)(threadIdx.x & (64u * G - 1u)); }
   __device__ __forceinline__ int group() const { return group_; }
@@ -73,15 +85,24 @@ struct DeviceWave {
 #endif
 
 // One workgroup = one team = K+1 polynomial groups of G waves = one LWE sample.
-// LDS (dynamic, 16-B aligned base, no static LDS): [ twiddles N x 8 B ][ group c: transpose/exchange
-// buffer N x 8 B | accumulator polynomial N x 4 B ] for c = 0..K
+// LDS (dynamic, 16-B aligned base, no static LDS): [ twiddles (N+2) x 8 B ][ group c: EXB transpose/
+// exchange buffers of N x 8 B | accumulator polynomial N x 4 B ] for c = 0..K
+// Exchange buffers per group: two (one team barrier per gadget level instead of two) where LDS has
+// room at the occupancy the registers allow -- N = 512: 4 teams of k = 2 need 139 KiB; N = 2048: one
+// team per CU, 136 KiB -- but not N = 1024, where 4 teams per CU would need 192 KiB.
+template <int LOGN>
+struct ExchangeBuffersOf {
+  static constexpr int value = (LOGN == 10) ? 1 : 2;
+};
+
 template <int LOGN, int K>
 struct TeamCfg {
   static constexpr int N = 1 << LOGN;
   static constexpr int G = GroupOf<LOGN>::value;
+  static constexpr int EXB = ExchangeBuffersOf<LOGN>::value;
   static constexpr int kWaves = (K + 1) * G;
   static constexpr int kThreads = kWaves * 64;
-  static constexpr unsigned kGroupLds = (unsigned)N * 8u + (unsigned)N * 4u;
+  static constexpr unsigned kGroupLds = (unsigned)N * 8u * EXB + (unsigned)N * 4u;
   static constexpr size_t kTwBytes = (size_t)ntt_twiddle_words(N) * 8;  // multiple of 16
   static constexpr size_t kLds = kTwBytes + (size_t)(K + 1) * kGroupLds;
   static constexpr int kMinWavesGl = (NttShape<LOGN, G>::kE == 8) ? 3 : TFHE_WAVES_PER_SIMD_GL;
@@ -89,21 +110,22 @@ struct TeamCfg {
 };
 
 template <class F, int LOGN, int K>
-__device__ __forceinline__ DeviceWave<typename F::elem, GroupOf<LOGN>::value> make_wave(
-    unsigned char* smem, const typename F::elem* tw_global) {
+__device__ __forceinline__ DeviceWave<typename F::elem, GroupOf<LOGN>::value, ExchangeBuffersOf<LOGN>::value>
+make_wave(unsigned char* smem, const typename F::elem* tw_global) {
   typedef typename F::elem elem;
   using C = TeamCfg<LOGN, K>;
   elem* tw = reinterpret_cast<elem*>(smem);
   for (int i = threadIdx.x; i < ntt_twiddle_words(C::N); i += blockDim.x) tw[i] = tw_global[i];
   __syncthreads();
-  DeviceWave<elem, C::G> w;
+  DeviceWave<elem, C::G, C::EXB> w;
   w.group_ = (int)(threadIdx.x / (64u * C::G));
   w.group_stride_ = C::kGroupLds;
+  w.buffer_bytes_ = (unsigned)C::N * 8u;
   w.team_base_ = smem + C::kTwBytes;
   unsigned char* base = w.team_base_ + (size_t)w.group_ * C::kGroupLds;
   w.tw_ = tw;
   w.scratch_ = reinterpret_cast<elem*>(base);
-  w.acc_ = reinterpret_cast<u32*>(base + (size_t)C::N * 8);
+  w.acc_ = reinterpret_cast<u32*>(base + (size_t)C::N * 8 * C::EXB);
   return w;
 }
 
@@ -135,6 +157,7 @@ __global__ void __launch_bounds__(256) bsk_prepare_kernel(const typename F::elem
   DeviceWave<elem, G> w;
   w.group_ = 0;
   w.group_stride_ = 0;
+  w.buffer_bytes_ = 0;
   w.team_base_ = nullptr;
   w.tw_ = twl;
   w.scratch_ = reinterpret_cast<elem*>(g_smem + (size_t)ntt_twiddle_words(N) * 8 + (size_t)group * N * 8);
@@ -426,6 +449,7 @@ __global__ void __launch_bounds__(256) glwe_body_kernel(const typename F::elem* 
   DeviceWave<elem, G> w;
   w.group_ = 0;
   w.group_stride_ = 0;
+  w.buffer_bytes_ = 0;
   w.team_base_ = nullptr;
   w.tw_ = twl;
   w.scratch_ = reinterpret_cast<elem*>(g_smem + (size_t)ntt_twiddle_words(N) * 8 + (size_t)group * N * 8);

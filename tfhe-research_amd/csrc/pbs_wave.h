@@ -147,11 +147,19 @@ TFHE_HD void external_product_team(const Ctx& c, const PbsParams& P, const typen
     const int s = idx / PARTS, q = idx % PARTS;
     return ggsw + (((size_t)(s * P.levels + level) * (K + 1) + me) * PARTS + q) * N;
   };
+  // Spectrum exchange through LDS.  With ONE buffer per group a level needs two team barriers
+  // (publish -> consume -> the next transform reuses the buffer).  With TWO buffers level t works in
+  // buffer t & 1: whoever still reads buffer (t-1) & 1 is not disturbed, and buffer t & 1 was last
+  // read in the MAC of level t-2, which every wave left before the barrier of level t-1 -- one
+  // barrier per level, plus one at the end of the product (the first level of the next product
+  // writes buffer 0 again).  The inverse transforms run in buffer levels & 1 under the same rule.
+  const bool two = c.exchange_buffers() == 2;
   elem kbuf[2][CH];
 #pragma unroll 1
   for (u32 t = 0; t < P.levels; ++t) {  // limbs LSB -> MSB; level index counts from the MSB
     const u32 level = P.levels - 1 - t;
     const u32 shift = P.first_shift + P.log_base * t;
+    const Ctx cl = c.with_exchange_buffer(two ? (int)(t & 1u) : 0);
     {
       const elem* tile = tile_ptr(level, 0);
 #pragma unroll
@@ -169,11 +177,12 @@ TFHE_HD void external_product_team(const Ctx& c, const PbsParams& P, const typen
         work[r] = F::from_digit(digit);
       }
       // digits are tiny (|d| <= B <= 2^F::kSmallBits, enforced when the context picks the field):
-      // the first butterfly stage uses F::mul_small
-      ntt_forward<F, LOGN, G, true>(c, work);
+      // the first butterfly stage uses F::mul_small.  A team barrier precedes every level (the
+      // caller's for level 0, the previous level's below) and nobody reads this buffer after it.
+      ntt_forward<F, LOGN, G, true, true>(cl, work);
       // publish: element r of thread tid at exchange_slot(tid, r) -- inside my wave's own part of
       // the buffer (wave_ntt.h), conflict-free 8-byte accesses
-      elem* mine = c.scratch();
+      elem* mine = cl.scratch();
 #pragma unroll
       for (int r = 0; r < E; ++r) mine[exchange_slot<LOGN, G>(lane, r)] = work[r];
     }
@@ -189,7 +198,7 @@ TFHE_HD void external_product_team(const Ctx& c, const PbsParams& P, const typen
 #pragma unroll
         for (int r = 0; r < CH; ++r) kbuf[nxt][r] = tile[spectrum_slot<LOGN, G>(lane, nr0 + r)];
       }
-      const elem* spec = c.scratch_of(s);
+      const elem* spec = cl.scratch_of(s);
       elem d[CH];
 #pragma unroll
       for (int r = 0; r < CH; ++r) d[r] = spec[exchange_slot<LOGN, G>(lane, r0 + r)];
@@ -198,14 +207,15 @@ TFHE_HD void external_product_team(const Ctx& c, const PbsParams& P, const typen
       for (int r = 0; r < CH; ++r)
         accum[q][r0 + r] = F::add(accum[q][r0 + r], F::mul(d[r], kbuf[cur][r]));
     });
-    c.team_sync();  // everyone is done reading before the next transform reuses the buffers
+    if (!two) c.team_sync();  // everyone is done reading before the next transform reuses the buffer
   }
 
+  const Ctx ci = c.with_exchange_buffer(two ? (int)(P.levels & 1u) : 0);
   static_for<0, PARTS>([&](auto part_c) {
     constexpr int q = decltype(part_c)::value;
 #pragma unroll
     for (int r = 0; r < E; ++r) accum[q][r] = F::before_inverse(accum[q][r]);
-    ntt_inverse<F, LOGN, G>(c, accum[q]);
+    ntt_inverse<F, LOGN, G>(ci, accum[q]);
   });
 #pragma unroll
   for (int r = 0; r < E; ++r) {
@@ -214,6 +224,10 @@ TFHE_HD void external_product_team(const Ctx& c, const PbsParams& P, const typen
     for (int q = 0; q < PARTS; ++q) parts[q] = accum[q][r];
     out(r * T + lane, F::finish(parts));
   }
+  // two buffers: the MAC reads of the last level must be over before a following product (or any
+  // other user of the buffers) writes buffer 0; this barrier also orders the out() stores of the
+  // whole team.  One buffer: the last level already ended with a barrier.
+  if (two) c.team_sync();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -262,7 +276,9 @@ TFHE_HD void blind_rotate_team(const Ctx& c, const PbsParams& P, const u32* lwe 
     // all rotated reads of acc happen before the first inverse transform: in-place update is safe
     auto out = [&](int j, u32 value) { acc[j] += value; };
     external_product_team<F, LOGN, K, G>(c, P, bsk + (size_t)i * ggsw_words, src, out);
-    c.poly_sync();  // G > 1: the other wave of my group reads what I just wrote
+    // G > 1: the other waves of my group read what I just wrote (with two exchange buffers the
+    // product already ended with a team barrier)
+    if (c.exchange_buffers() != 2) c.poly_sync();
   }
 }
 

@@ -33,6 +33,8 @@
 // Ctx (GPU: DeviceWave in kernels.hip; CPU tests: the SIMT emulator in tests/emu) provides
 //   int tid() const;  void poly_sync() const;  void wave_sync() const;  elem* scratch() const;
 //   const elem* twiddles() const;
+// and, for the team code in pbs_wave.h, int exchange_buffers() const (1 or 2 LDS buffers per group)
+// and Ctx with_exchange_buffer(int i) const (a copy whose scratch()/scratch_of() use buffer i).
 #pragma once
 #include "field_fp.h"
 #include "field_gl.h"
@@ -117,7 +119,10 @@ TFHE_HD int exchange_slot(int tid, int r) {
 // Invariant every user of the buffer keeps: reads that leave the own region (here, and the team's
 // spectrum exchange in pbs_wave.h) are followed by a workgroup barrier before the next write.
 // G == 1: everything is wave-local.
-template <class F, int LOGN, int G, int LO_FROM, int LO_TO, class Ctx>
+// SKIP_LEAD: the caller guarantees that a workgroup barrier already separates every earlier read of
+// the buffer from this call (no read of it since), so the leading barrier of a cross-writing
+// transpose is dropped.
+template <class F, int LOGN, int G, int LO_FROM, int LO_TO, bool SKIP_LEAD = false, class Ctx>
 TFHE_HD void ntt_transpose(const Ctx& c, typename F::elem (&x)[NttShape<LOGN, G>::kE]) {
   constexpr int E = NttShape<LOGN, G>::kE;
   constexpr bool WRITES_CROSS = G > 1 && LO_FROM > 6;
@@ -125,7 +130,7 @@ TFHE_HD void ntt_transpose(const Ctx& c, typename F::elem (&x)[NttShape<LOGN, G>
   static_assert(!(WRITES_CROSS && READS_CROSS), "one of the two windows is a low one");
   typename F::elem* buf = c.scratch();
   const int tid = c.tid();
-  if (WRITES_CROSS) c.poly_sync();
+  if (WRITES_CROSS && !SKIP_LEAD) c.poly_sync();
 #pragma unroll
   for (int r = 0; r < E; ++r) buf[ntt_swizzle<LOGN, G>(ntt_index<LOGN, G, LO_FROM>(tid, r))] = x[r];
   if (WRITES_CROSS || READS_CROSS) c.poly_sync(); else c.wave_sync();
@@ -204,11 +209,12 @@ TFHE_HD void ntt_pass_inverse(const Ctx& c, typename F::elem (&x)[NttShape<LOGN,
 
 // in: x[r] = a[r*64G + tid].  out: x[r] = A_bitrev[tid*E + r].
 // SMALL_INPUT: every |x[r]| <= 2^F::kSmallBits on entry (gadget digits).
-template <class F, int LOGN, int G, bool SMALL_INPUT = false, class Ctx>
+// AFTER_BARRIER: nobody has read the buffer since the last workgroup barrier (see ntt_transpose).
+template <class F, int LOGN, int G, bool SMALL_INPUT = false, bool AFTER_BARRIER = false, class Ctx>
 TFHE_HD void ntt_forward(const Ctx& c, typename F::elem (&x)[NttShape<LOGN, G>::kE]) {
   using S = NttShape<LOGN, G>;
   ntt_pass_forward<F, LOGN, G, S::kLo1, LOGN - 1, S::kTBits, SMALL_INPUT>(c, x);
-  ntt_transpose<F, LOGN, G, S::kLo1, S::kLo2>(c, x);
+  ntt_transpose<F, LOGN, G, S::kLo1, S::kLo2, AFTER_BARRIER>(c, x);
   ntt_pass_forward<F, LOGN, G, S::kLo2, S::kTBits - 1, S::kLo2, false>(c, x);
   ntt_transpose<F, LOGN, G, S::kLo2, S::kLo3>(c, x);
   ntt_pass_forward<F, LOGN, G, S::kLo3, S::kLo2 - 1, S::kLo3, false>(c, x);
