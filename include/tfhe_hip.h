@@ -38,6 +38,7 @@ extern "C" {
 #define TFHE_ERR_INVALID_ARGUMENT 5 /* null pointer / bad count / value the reference assert!s on */
 #define TFHE_ERR_NO_DEVICE 6        /* no usable GPU: this library has no CPU fallback */
 #define TFHE_ERR_EXACTNESS 7        /* parameter set exceeds the exact-NTT bound */
+#define TFHE_ERR_IO 8               /* file missing, truncated, not in this format, or corrupt */
 
 /* decomposer.rs:2-6 DecomposerParams */
 typedef struct tfhe_decomposer_params {
@@ -281,6 +282,31 @@ int tfhe_context_set_bootstrap_order(tfhe_context *ctx, int ks_first);
  * to the hot path and to keygen; identical bits to mode 0 whenever log_base divides 32.  Keys made
  * in one mode must be used in that mode. */
 int tfhe_context_set_decomposer_alignment(tfhe_context *ctx, int aligned);
+
+/* ---- on-disk format for keys and ciphertexts (the reference has none) -----------
+ * One array per file, host side only (no GPU needed), little endian:
+ *   0   char[8]  magic "TFHEAMD\1"
+ *   8   u32      kind (TFHE_FILE_*)          12  u32  flags (bit 0: aligned decomposer)
+ *   16  u32[12]  tfhe_params (k, log2 N, n, padding_bits, log_p, log_q, ks{log_base, levels, log_q},
+ *                pbs{log_base, levels, log_q})
+ *   64  u32      ndims (1..4)                68  u32[4] dims (row-major, unused = 1)   84  u32  0
+ *   88  u64      payload words (= product of dims)
+ *   96  u64      FNV-1a 64 of the payload bytes
+ *   104 u32[]    payload: the array exactly as the ABI takes it (reference layouts)
+ * Readers refuse a wrong magic, a size that disagrees with the header, and a checksum mismatch
+ * (TFHE_ERR_IO); comparing the stored parameters with the context's is the caller's job
+ * (tfhe_file_read_header hands them back). */
+#define TFHE_FILE_BSK 1   /* [n][(k+1)l][k+1][N] */
+#define TFHE_FILE_KSK 2   /* [kN*l_ks][n+1] */
+#define TFHE_FILE_LWE 3   /* [batch][dim+1] */
+#define TFHE_FILE_GLWE 4  /* [batch][k+1][N] */
+#define TFHE_FILE_GGSW 5  /* [count][(k+1)l][k+1][N] */
+#define TFHE_FILE_FLAG_ALIGNED 1u
+int tfhe_file_write(const char *path, uint32_t kind, const tfhe_params *params, uint32_t flags,
+                    const uint32_t *dims, uint32_t ndims, const uint32_t *data);
+int tfhe_file_read_header(const char *path, uint32_t *kind, tfhe_params *params, uint32_t *flags,
+                          uint32_t dims[4], uint32_t *ndims, uint64_t *words);
+int tfhe_file_read(const char *path, uint32_t *data, uint64_t words);
 
 /* ---- introspection for benchmarks --------------------------------------------------------- */
 /* Time of the blind-rotation kernel of the most recent bootstrap/blind_rotate call, measured with

@@ -24,9 +24,11 @@ TFHE_OK = 0
 STATUS_NAMES = {
     0: "TFHE_OK", 1: "TFHE_ERR_INVALID_PARAMS", 2: "TFHE_ERR_UNSUPPORTED", 3: "TFHE_ERR_NO_KEY",
     4: "TFHE_ERR_HIP", 5: "TFHE_ERR_INVALID_ARGUMENT", 6: "TFHE_ERR_NO_DEVICE", 7: "TFHE_ERR_EXACTNESS",
+    8: "TFHE_ERR_IO",
 }
 (TFHE_ERR_INVALID_PARAMS, TFHE_ERR_UNSUPPORTED, TFHE_ERR_NO_KEY, TFHE_ERR_HIP, TFHE_ERR_INVALID_ARGUMENT,
- TFHE_ERR_NO_DEVICE, TFHE_ERR_EXACTNESS) = range(1, 8)
+ TFHE_ERR_NO_DEVICE, TFHE_ERR_EXACTNESS, TFHE_ERR_IO) = range(1, 9)
+FILE_BSK, FILE_KSK, FILE_LWE, FILE_GLWE, FILE_GGSW = 1, 2, 3, 4, 5
 DECOMPOSER_PBS, DECOMPOSER_KS = 0, 1
 BACKEND_AUTO, BACKEND_GOLDILOCKS, BACKEND_FP64, BACKEND_GOLDILOCKS_SPLIT = 0, 1, 2, 3
 
@@ -202,6 +204,57 @@ def construct_test_vector_boolean(params: TfheParams, truth) -> np.ndarray:
     if st:
         raise TfheError(st, "construct_test_vector_boolean")
     return out
+
+
+# -- on-disk format (host only; include/tfhe_hip.h "on-disk format") -----------------------------
+def save_array(path: str, kind: int, params: TfheParams, array, aligned: bool = False) -> None:
+    """One key or ciphertext array per file, in the layout the ABI takes it."""
+    a = _np(array)
+    assert 1 <= a.ndim <= 4
+    dims = (C.c_uint32 * a.ndim)(*a.shape)
+    cp = params._c()
+    st = lib().tfhe_file_write(os.fsencode(path), C.c_uint32(kind), C.byref(cp), C.c_uint32(int(aligned)),
+                               dims, C.c_uint32(a.ndim), _hp(a))
+    if st:
+        raise TfheError(st, f"writing {path}")
+
+
+def load_array(path: str):
+    """-> (kind, TfheParams, aligned, array); raises TfheError(TFHE_ERR_IO) on a foreign, truncated
+    or corrupt file."""
+    kind, flags, ndims, words = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint64()
+    dims = (C.c_uint32 * 4)()
+    cp = _CParams()
+    st = lib().tfhe_file_read_header(os.fsencode(path), C.byref(kind), C.byref(cp), C.byref(flags), dims,
+                                     C.byref(ndims), C.byref(words))
+    if st:
+        raise TfheError(st, f"reading {path}")
+    out = np.zeros(tuple(dims[i] for i in range(ndims.value)), dtype=np.uint32)
+    st = lib().tfhe_file_read(os.fsencode(path), _hp(out), C.c_uint64(out.size))
+    if st:
+        raise TfheError(st, f"reading {path}")
+    params = TfheParams(cp.glwe_dimension, cp.glwe_poly_degree, cp.lwe_dimension,
+                        DecomposerParams(cp.pbs_decomposer.log_base, cp.pbs_decomposer.levels),
+                        DecomposerParams(cp.ks_decomposer.log_base, cp.ks_decomposer.levels),
+                        log_p=cp.log_p, padding_bits=cp.padding_bits)
+    return kind.value, params, bool(flags.value & 1), out
+
+
+def save_bootstrapping_key(prefix: str, params: TfheParams, bsk, ksk, aligned: bool = False) -> None:
+    """BootstrappingKey (bootstrapping.rs:18-21) as <prefix>.bsk + <prefix>.ksk"""
+    save_array(prefix + ".bsk", FILE_BSK, params, bsk, aligned)
+    save_array(prefix + ".ksk", FILE_KSK, params, ksk, aligned)
+
+
+def load_bootstrapping_key(prefix: str, params: TfheParams, aligned: bool = False):
+    """-> (bsk, ksk); refuses files written for other parameters or the other decomposer alignment"""
+    out = []
+    for ext, want in ((".bsk", FILE_BSK), (".ksk", FILE_KSK)):
+        kind, p, al, arr = load_array(prefix + ext)
+        if kind != want or p != params or al != aligned:
+            raise TfheError(TFHE_ERR_INVALID_PARAMS, f"{prefix + ext} holds kind {kind} for {p} (aligned={al})")
+        out.append(arr)
+    return tuple(out)
 
 
 def params_validate(params: TfheParams) -> int:

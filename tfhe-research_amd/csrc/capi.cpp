@@ -263,6 +263,7 @@ const char* tfhe_status_string(int status) {
     case TFHE_ERR_INVALID_ARGUMENT: return "invalid argument";
     case TFHE_ERR_NO_DEVICE: return "no GPU device (this library has no CPU path)";
     case TFHE_ERR_EXACTNESS: return "parameter set exceeds the exact-NTT bound";
+    case TFHE_ERR_IO: return "file missing, truncated, not in this format, or corrupt";
     default: return "unknown status";
   }
 }
@@ -1073,6 +1074,144 @@ int tfhe_bootstrapping_key_gen(tfhe_context* ctx, const uint32_t* lwe_sk, const 
   }
   if (d_bsk) (void)hipFree(d_bsk);
   if (d_ksk) (void)hipFree(d_ksk);
+  return st;
+}
+
+// ---------------------------------------------------------------------------------- on-disk format
+namespace {
+
+constexpr char kFileMagic[8] = {'T', 'F', 'H', 'E', 'A', 'M', 'D', '\1'};
+constexpr size_t kFileHeaderBytes = 104;
+
+struct FileHeader {
+  u32 kind = 0, flags = 0;
+  u32 params[12] = {};
+  u32 ndims = 0, dims[4] = {1, 1, 1, 1};
+  u64 words = 0, checksum = 0;
+};
+
+u64 fnv1a64(const unsigned char* p, size_t len, u64 h = 0xcbf29ce484222325ull) {
+  for (size_t i = 0; i < len; ++i) {
+    h ^= p[i];
+    h *= 0x100000001b3ull;
+  }
+  return h;
+}
+
+void put_u32(unsigned char* p, u32 v) { for (int i = 0; i < 4; ++i) p[i] = (unsigned char)(v >> (8 * i)); }
+void put_u64(unsigned char* p, u64 v) { for (int i = 0; i < 8; ++i) p[i] = (unsigned char)(v >> (8 * i)); }
+u32 get_u32(const unsigned char* p) { u32 v = 0; for (int i = 0; i < 4; ++i) v |= (u32)p[i] << (8 * i); return v; }
+u64 get_u64(const unsigned char* p) { u64 v = 0; for (int i = 0; i < 8; ++i) v |= (u64)p[i] << (8 * i); return v; }
+
+void params_to_words(const tfhe_params& p, u32 out[12]) {
+  const u32 w[12] = {p.glwe_dimension, p.glwe_poly_degree, p.lwe_dimension, p.padding_bits, p.log_p, p.log_q,
+                     p.ks_decomposer.log_base, p.ks_decomposer.levels, p.ks_decomposer.log_q,
+                     p.pbs_decomposer.log_base, p.pbs_decomposer.levels, p.pbs_decomposer.log_q};
+  std::memcpy(out, w, sizeof(w));
+}
+
+void words_to_params(const u32 w[12], tfhe_params* p) {
+  p->glwe_dimension = w[0];
+  p->glwe_poly_degree = w[1];
+  p->lwe_dimension = w[2];
+  p->padding_bits = w[3];
+  p->log_p = w[4];
+  p->log_q = w[5];
+  p->ks_decomposer = {w[6], w[7], w[8]};
+  p->pbs_decomposer = {w[9], w[10], w[11]};
+}
+
+int read_header(std::FILE* f, FileHeader* h) {
+  unsigned char b[kFileHeaderBytes];
+  if (std::fread(b, 1, sizeof(b), f) != sizeof(b)) return TFHE_ERR_IO;
+  if (std::memcmp(b, kFileMagic, 8) != 0) return TFHE_ERR_IO;
+  h->kind = get_u32(b + 8);
+  h->flags = get_u32(b + 12);
+  for (int i = 0; i < 12; ++i) h->params[i] = get_u32(b + 16 + 4 * i);
+  h->ndims = get_u32(b + 64);
+  for (int i = 0; i < 4; ++i) h->dims[i] = get_u32(b + 68 + 4 * i);
+  h->words = get_u64(b + 88);
+  h->checksum = get_u64(b + 96);
+  if (h->kind < TFHE_FILE_BSK || h->kind > TFHE_FILE_GGSW || h->ndims == 0 || h->ndims > 4) return TFHE_ERR_IO;
+  u64 prod = 1;
+  for (u32 i = 0; i < 4; ++i) {
+    if (h->dims[i] == 0 || (i >= h->ndims && h->dims[i] != 1)) return TFHE_ERR_IO;
+    if (prod > (~0ull) / h->dims[i]) return TFHE_ERR_IO;
+    prod *= h->dims[i];
+  }
+  if (prod != h->words) return TFHE_ERR_IO;
+  return TFHE_OK;
+}
+
+}  // namespace
+
+int tfhe_file_write(const char* path, uint32_t kind, const tfhe_params* params, uint32_t flags,
+                    const uint32_t* dims, uint32_t ndims, const uint32_t* data) {
+  if (!path || !params || !dims || !data || ndims == 0 || ndims > 4 || kind < TFHE_FILE_BSK || kind > TFHE_FILE_GGSW)
+    return TFHE_ERR_INVALID_ARGUMENT;
+  u64 words = 1;
+  for (u32 i = 0; i < ndims; ++i) {
+    if (dims[i] == 0 || words > (~0ull) / dims[i]) return TFHE_ERR_INVALID_ARGUMENT;
+    words *= dims[i];
+  }
+  unsigned char b[kFileHeaderBytes] = {};
+  std::memcpy(b, kFileMagic, 8);
+  put_u32(b + 8, kind);
+  put_u32(b + 12, flags);
+  u32 pw[12];
+  params_to_words(*params, pw);
+  for (int i = 0; i < 12; ++i) put_u32(b + 16 + 4 * i, pw[i]);
+  put_u32(b + 64, ndims);
+  for (u32 i = 0; i < 4; ++i) put_u32(b + 68 + 4 * i, i < ndims ? dims[i] : 1u);
+  put_u64(b + 88, words);
+  // payload is written as little-endian u32 words; this library only targets little-endian hosts,
+  // so the in-memory bytes are the file bytes
+  put_u64(b + 96, fnv1a64(reinterpret_cast<const unsigned char*>(data), (size_t)words * sizeof(u32)));
+  std::FILE* f = std::fopen(path, "wb");
+  if (!f) return TFHE_ERR_IO;
+  bool ok = std::fwrite(b, 1, sizeof(b), f) == sizeof(b) &&
+            std::fwrite(data, sizeof(u32), (size_t)words, f) == (size_t)words;
+  ok = (std::fclose(f) == 0) && ok;
+  return ok ? TFHE_OK : TFHE_ERR_IO;
+}
+
+int tfhe_file_read_header(const char* path, uint32_t* kind, tfhe_params* params, uint32_t* flags,
+                          uint32_t dims[4], uint32_t* ndims, uint64_t* words) {
+  if (!path) return TFHE_ERR_INVALID_ARGUMENT;
+  std::FILE* f = std::fopen(path, "rb");
+  if (!f) return TFHE_ERR_IO;
+  FileHeader h;
+  int st = read_header(f, &h);
+  if (st == TFHE_OK) {  // the payload must be all there, and nothing after it
+    if (std::fseek(f, 0, SEEK_END) != 0) st = TFHE_ERR_IO;
+    const long end = std::ftell(f);
+    if (end < 0 || (u64)end != kFileHeaderBytes + h.words * sizeof(u32)) st = TFHE_ERR_IO;
+  }
+  std::fclose(f);
+  if (st) return st;
+  if (kind) *kind = h.kind;
+  if (params) words_to_params(h.params, params);
+  if (flags) *flags = h.flags;
+  if (dims) std::memcpy(dims, h.dims, sizeof(h.dims));
+  if (ndims) *ndims = h.ndims;
+  if (words) *words = h.words;
+  return TFHE_OK;
+}
+
+int tfhe_file_read(const char* path, uint32_t* data, uint64_t words) {
+  if (!path || !data) return TFHE_ERR_INVALID_ARGUMENT;
+  std::FILE* f = std::fopen(path, "rb");
+  if (!f) return TFHE_ERR_IO;
+  FileHeader h;
+  int st = read_header(f, &h);
+  if (st == TFHE_OK && h.words != words) st = TFHE_ERR_INVALID_ARGUMENT;
+  if (st == TFHE_OK && std::fread(data, sizeof(u32), (size_t)words, f) != (size_t)words) st = TFHE_ERR_IO;
+  unsigned char extra;
+  if (st == TFHE_OK && std::fread(&extra, 1, 1, f) != 0) st = TFHE_ERR_IO;
+  std::fclose(f);
+  if (st == TFHE_OK &&
+      fnv1a64(reinterpret_cast<const unsigned char*>(data), (size_t)words * sizeof(u32)) != h.checksum)
+    st = TFHE_ERR_IO;
   return st;
 }
 
