@@ -314,6 +314,10 @@ int tfhe_file_read(const char *path, uint32_t *data, uint64_t words);
  * tfhe_context_set_timing(ctx, 1): the _device calls then record events (still no sync). */
 int tfhe_context_set_timing(tfhe_context *ctx, int enable);
 int tfhe_last_kernel_ms(tfhe_context *ctx, float *blind_rotate_ms, float *key_switch_ms);
+/* HBM roofline measured on this device now: a 16-byte-per-lane stream copy of `bytes` (two scratch
+ * buffers are allocated and freed inside), `reps` timed launches on the context's stream;
+ * *gb_per_s = (bytes read + bytes written) / time.  Synchronises. */
+int tfhe_measure_hbm_copy(tfhe_context *ctx, size_t bytes, int reps, double *gb_per_s);
 
 /* Library / build identification */
 const char *tfhe_version(void);

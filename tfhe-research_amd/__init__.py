@@ -344,6 +344,12 @@ class Context:
     def set_timing(self, enable: bool):
         self._check(lib().tfhe_context_set_timing(self._h, C.c_int(int(enable))))
 
+    def measure_hbm_copy(self, mib: int = 1024, reps: int = 10) -> float:
+        """GB/s (read + write) of a 16-byte-per-lane stream copy: the HBM roofline of this device now."""
+        out = C.c_double()
+        self._check(lib().tfhe_measure_hbm_copy(self._h, C.c_size_t(mib << 20), C.c_int(reps), C.byref(out)))
+        return out.value
+
     def last_kernel_ms(self):
         br, ks = C.c_float(), C.c_float()
         self._check(lib().tfhe_last_kernel_ms(self._h, C.byref(br), C.byref(ks)))

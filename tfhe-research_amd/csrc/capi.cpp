@@ -463,6 +463,34 @@ int tfhe_context_set_timing(tfhe_context* ctx, int enable) {
   return TFHE_OK;
 }
 
+int tfhe_measure_hbm_copy(tfhe_context* ctx, size_t bytes, int reps, double* gb_per_s) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  if (!gb_per_s || bytes < 16 || reps <= 0) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "bytes >= 16, reps >= 1");
+  bytes &= ~(size_t)15;
+  void *src = nullptr, *dst = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipError_t e = hipMalloc(&src, bytes);
+  if (e == hipSuccess) e = hipMalloc(&dst, bytes);
+  if (e == hipSuccess) e = hipMemsetAsync(src, 1, bytes, ctx->stream);
+  if (e == hipSuccess) e = hipEventCreate(&e0);
+  if (e == hipSuccess) e = hipEventCreate(&e1);
+  for (int i = 0; i < 2 && e == hipSuccess; ++i) e = launch::stream_copy(ctx->stream, src, dst, bytes);
+  if (e == hipSuccess) e = hipEventRecord(e0, ctx->stream);
+  for (int i = 0; i < reps && e == hipSuccess; ++i) e = launch::stream_copy(ctx->stream, src, dst, bytes);
+  if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
+  if (e == hipSuccess) e = hipEventSynchronize(e1);
+  float ms = 0.f;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (src) (void)hipFree(src);
+  if (dst) (void)hipFree(dst);
+  if (e != hipSuccess) return hip_fail(ctx, e, "hbm copy probe");
+  *gb_per_s = 2.0 * (double)bytes * reps / ((double)ms * 1e-3) / 1e9;  // read + write
+  return TFHE_OK;
+}
+
 int tfhe_last_kernel_ms(tfhe_context* ctx, float* blind_rotate_ms, float* key_switch_ms) {
   int st = check_ctx(ctx);
   if (st) return st;

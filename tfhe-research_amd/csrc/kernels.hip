@@ -87,12 +87,13 @@ struct DeviceWave {
 // One workgroup = one team = K+1 polynomial groups of G waves = one LWE sample.
 // LDS (dynamic, 16-B aligned base, no static LDS): [ twiddles (N+2) x 8 B ][ group c: EXB transpose/
 // exchange buffers of N x 8 B | accumulator polynomial N x 4 B ] for c = 0..K
-// Exchange buffers per group: two (one team barrier per gadget level instead of two) where LDS has
-// room at the occupancy the registers allow -- N = 512: 4 teams of k = 2 need 139 KiB; N = 2048: one
-// team per CU, 136 KiB -- but not N = 1024, where 4 teams per CU would need 192 KiB.
+// Exchange buffers per group: two (one team barrier per gadget level instead of two) at N = 2048,
+// where one 12-wave team per CU leaves LDS to spare and the barriers of a 768-thread workgroup are
+// dear (+5 % at cfg5).  One at N = 1024 (4 teams per CU would need 192 KiB with two) and at N = 512
+// (two fit, 139 KiB, but measured no gain at cfg3: 114.6 vs 116.1 ms per 4096 gates).
 template <int LOGN>
 struct ExchangeBuffersOf {
-  static constexpr int value = (LOGN == 10) ? 1 : 2;
+  static constexpr int value = (LOGN >= 11) ? 2 : 1;
 };
 
 template <int LOGN, int K>
@@ -506,6 +507,23 @@ __global__ void ggsw_add_gadget_kernel(u32* ggsw, size_t ggsw_count, u32 k, u32 
   }
 }
 
+// HBM roofline probe: 16-byte-per-lane stream copy (the "float4 copy" of MI355X_MICROARCH.md).
+// A workgroup moves one contiguous 16 KiB piece: every lane issues its 4 loads before the first
+// store, so 64 B per lane are in flight; loads and stores are non-temporal (nothing is reused).
+constexpr int kCopyUnroll = 4;
+typedef unsigned int copy_vec4 __attribute__((ext_vector_type(4)));  // 16 bytes, what the builtins accept
+__global__ void __launch_bounds__(256) stream_copy_kernel(const copy_vec4* __restrict__ src,
+                                                         copy_vec4* __restrict__ dst, size_t count) {
+  const size_t base = (size_t)blockIdx.x * (256 * kCopyUnroll) + threadIdx.x;
+  copy_vec4 v[kCopyUnroll];
+#pragma unroll
+  for (int i = 0; i < kCopyUnroll; ++i)
+    if (base + (size_t)i * 256 < count) v[i] = __builtin_nontemporal_load(&src[base + (size_t)i * 256]);
+#pragma unroll
+  for (int i = 0; i < kCopyUnroll; ++i)
+    if (base + (size_t)i * 256 < count) __builtin_nontemporal_store(v[i], &dst[base + (size_t)i * 256]);
+}
+
 inline int grid_for(size_t work, int block) {
   size_t g = (work + block - 1) / block;
   if (g > 2048) g = 2048;  // 256 CUs x 8: grid-stride the rest
@@ -742,6 +760,14 @@ hipError_t sample_extract(hipStream_t s, u32 log_n, u32 k, const u32* glwe, size
   const size_t total = batch * (((size_t)k << log_n) + 1);
   hipLaunchKernelGGL(sample_extract_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, log_n, k,
                      glwe, batch, sample_index, lwe_out);
+  return hipGetLastError();
+}
+
+hipError_t stream_copy(hipStream_t s, const void* src, void* dst, size_t bytes) {
+  const size_t count = bytes / sizeof(copy_vec4);
+  const size_t per_block = 256 * kCopyUnroll;
+  hipLaunchKernelGGL(stream_copy_kernel, dim3((unsigned)((count + per_block - 1) / per_block)), dim3(256), 0, s,
+                     static_cast<const copy_vec4*>(src), static_cast<copy_vec4*>(dst), count);
   return hipGetLastError();
 }
 

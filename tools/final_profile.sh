@@ -1,0 +1,13 @@
+set -u
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/final; mkdir -p $O
+python bench.py > $O/bench_cfg2.json.log 2>$O/bench_cfg2.err && tail -c 600 $O/bench_cfg2.json.log && \
+python bench.py --workload cfg3 --gate nand --batch 65536 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_cfg3_nand.json.log 2>&1 && \
+python bench.py --workload cfg5 --batch 4096 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_cfg5_b4096.json.log 2>&1 && \
+python bench.py --workload cfg1 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_cfg1.json.log 2>&1 && \
+python bench.py --kernel external_product --no-cpu-baseline > $O/bench_ep_shared.json.log 2>&1 && \
+python bench.py --kernel external_product --ggsw-per-sample --no-cpu-baseline > $O/bench_ep_streamed.json.log 2>&1 && \
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_cfg2_torchrun1.json.log 2>&1 && \
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/stats.log 2>&1) && \
+find $O/stats -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_cfg2.csv \; && head -5 $O/kernel_stats_cfg2.csv && \
+bash tools/profile_pmc.sh final/pmc
