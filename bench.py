@@ -80,10 +80,10 @@ def pmc_traffic(kernel: str, workload: str, batch: int):
         with open(path) as f:
             rec = json.load(f)
     except (OSError, ValueError):
-        return None, None
+        return None, None, None
     if rec.get("kernel") == kernel and rec.get("workload") == f"{workload} batch {batch}":
-        return rec["traffic_bytes_per_launch"], rec.get("source")
-    return None, None
+        return rec["traffic_bytes_per_launch"], rec.get("source"), rec.get("valu") or None
+    return None, None, None
 
 WORKLOADS = {
     # name: (k, logN, n, (pbs logB, l), (ks logB, l), log_p, default batch)
@@ -320,7 +320,7 @@ def main():
     algo_bytes = ext_products * params.external_product_bytes()
     achieved = algo_bytes / (br_avg * 1e-3) / 1e9
     kernel_name = f"blind_rotate_kernel<{backend_name},{logn},{k}>"
-    traffic, traffic_source = pmc_traffic(kernel_name, args.workload, batch)
+    traffic, traffic_source, valu_view = pmc_traffic(kernel_name, args.workload, batch)
     hbm_copy = measure_hbm_copy_gbs(torch, dev, ctx=ctx)
     result = {
         "metric": "homomorphic_gates_per_sec" if args.gate else "programmable_bootstraps_per_sec",
@@ -353,6 +353,7 @@ def main():
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
             "traffic_source": traffic_source,
+            "valu": valu_view,  # VALU-issue view from the same PMC passes (SURVEY 8d asks for both)
             "hbm_copy_measured_GBps": hbm_copy,
             "frac_of_measured_hbm": achieved / hbm_copy,
             "kernel_ms": br_avg,

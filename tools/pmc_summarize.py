@@ -44,7 +44,16 @@ if "GRBM_GUI_ACTIVE" in per and "SQ_INSTS_VALU" in per:
           f"{cyc * 1024 / per['SQ_INSTS_VALU']:.2f}")
 if "--json" in sys.argv and "FETCH_SIZE" in per and "WRITE_SIZE" in per:
     out = sys.argv[sys.argv.index("--json") + 1]
-    json.dump({"kernel": "blind_rotate_kernel<fp64-p42,10,1>", "workload": label,
+    valu = {}
+    if "GRBM_GUI_ACTIVE" in per and "SQ_INSTS_VALU" in per:
+        cpi = per["GRBM_GUI_ACTIVE"] / 8 * 1024 / per["SQ_INSTS_VALU"]
+        valu = {"valu_insts_per_external_product": per["SQ_INSTS_VALU"] / products,
+                "cycles_per_valu_inst_per_simd": cpi,
+                "issue_floor_cycles_per_inst": 5.3,
+                "valu_issue_frac": 5.3 / cpi,
+                "floor_source": "profiles/r01_dp_chain_latency_gfx950.txt (fp64 ops, 2 waves per SIMD)"}
+    # bench.py matches on "workload" == "<name> batch <batch>": keep it to exactly that
+    json.dump({"kernel": "blind_rotate_kernel<fp64-p42,10,1>", "workload": label.split(",")[0], "valu": valu,
                "fetch_size_kib": per["FETCH_SIZE"], "write_size_kib": per["WRITE_SIZE"],
                "traffic_bytes_per_launch": traffic,
                "note": "L2 fabric-side requests (Infinity-Cache hits included); varies with the drift of the teams inside an XCD",
