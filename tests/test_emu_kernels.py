@@ -303,3 +303,30 @@ def test_glwe_mask_dot_key_vs_oracle(emu, oracle, field, k, logn, g):
         assert np.array_equal(dec, samples[:, k])              # decrypt gives the error samples back
         for r in range(rows):
             assert np.array_equal(dec[r], oracle.decrypt_glwe_raw(params, sk, expect[r]))
+
+
+def test_key_word_split_has_no_signed_overflow(emu):
+    """w = 0x7FFFxxxx with a negative low half: hi must come out as -32768 (w - lo = 2^31 taken in
+    wrapping u32), found by the sanitizer run below."""
+    for w, lo, hi in ((0x7FFFD5ED, -10771, -32768), (0x7FFF8000, -32768, -32768), (0x80007FFF, 32767, -32768),
+                      (0xFFFFFFFF, -1, 0), (0x00010000, 0, 1), (0x7FFF7FFF, 32767, 32767)):
+        assert emu.emu_fp_from_key_word(C.c_uint32(w), 0) == float(lo)
+        assert emu.emu_fp_from_key_word(C.c_uint32(w), 1) == float(hi)
+        assert (lo + (hi << 16)) & 0xFFFFFFFF == w
+
+
+def test_device_headers_under_address_and_ub_sanitizers():
+    """tests/emu/sanitize_main.cpp: every shipped shape, field and exchange-buffer scheme through
+    bsk_prepare / external product / blind rotation / keygen with ASan + UBSan (CPU only: the GPU
+    pool has no sanitizer).  LDS is an exact-size heap buffer there, so a bad slot or twiddle index
+    is an error, and so is signed overflow or an out-of-range shift."""
+    exe = os.path.join(EMU_DIR, "sanitize")
+    src = os.path.join(EMU_DIR, "sanitize_main.cpp")
+    deps = [src, os.path.join(EMU_DIR, "emu.cpp")] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    if not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps):
+        subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fsanitize=address,undefined",
+                        "-fno-sanitize-recover=all", "-pthread", "-I", CSRC, src, "-o", exe], check=True)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
+    res = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert "sanitized run clean" in res.stdout

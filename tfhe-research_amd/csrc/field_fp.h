@@ -74,7 +74,9 @@ struct FpField {
   TFHE_HD static elem from_key_word(u32 w, int part) {
     const i32 lo = (i32)(int16_t)(w & 0xFFFFu);
     if (part == 0) return (double)lo;
-    return (double)(((i32)w - lo) >> 16);  // exact: the difference is a multiple of 2^16
+    // exact: the difference is a multiple of 2^16; taken in wrapping u32 (w = 0x7FFFxxxx with a
+    // negative low half gives 2^31, i.e. hi = -32768: |hi| <= 2^15 and lo + 2^16 hi = w mod 2^32)
+    return (double)((i32)(w - (u32)lo) >> 16);
   }
   TFHE_HD static elem before_inverse(elem a) { return reduce(a); }
   // exact integer t (|t| < 2^52) -> t mod 2^32

@@ -29,7 +29,9 @@ struct GlFieldT {
     if (PARTS == 1) return (elem)w;
     // signed 16-bit halves of the word taken as a signed 32-bit integer: w = lo + 2^16 hi (mod 2^32)
     const i32 lo = (i32)(int16_t)(w & 0xFFFFu);
-    return gl::from_i32((u32)(part == 0 ? lo : (((i32)w - lo) >> 16)));
+    // (w - lo) in wrapping u32: for w = 0x7FFFxxxx with a negative low half the difference is 2^31,
+    // i.e. hi = -32768 -- still |hi| <= 2^15 and lo + 2^16 hi = w (mod 2^32)
+    return gl::from_i32((u32)(part == 0 ? lo : ((i32)(w - (u32)lo) >> 16)));
   }
   // called on every accumulator before the inverse transform
   TFHE_HD static elem before_inverse(elem a) { return a; }
