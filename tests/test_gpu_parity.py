@@ -286,8 +286,13 @@ def test_full_size_cfg1_and_cfg5_single_sample(oracle):
         with m.Context(to_pkg_params(p)) as ctx:
             ctx.load_bootstrapping_key(bsk, ksk)
             out = ctx.bootstrap(lwe, tv)
+            # the full BASELINE batch (4096) built from these 4 rows in a scrambled order: every copy
+            # must reproduce the 4-row run, whichever workgroup / round / key-switch split it lands in
+            order = np.random.default_rng(17).integers(0, 4, size=4096)
+            big = ctx.bootstrap(lwe[order], tv)
         assert np.array_equal(out[3], out[0]), name
         assert np.array_equal(out[0], oracle.bootstrap(p, lwe[0], bsk, ksk, tv)), name
+        assert np.array_equal(big, out[order]), name
 
 
 def test_batch_4096_properties_cfg2(oracle):
