@@ -36,10 +36,17 @@ def _worker(rank, world, port, batch, width, q):
     full = torch.randint(-(1 << 31), (1 << 31) - 1, (batch, width), dtype=torch.int32, generator=g)
     tv = torch.arange(width, dtype=torch.int32)
     like = torch.empty(0, dtype=torch.int32)
+    # key upload: the root's read-only tensors reach every rank unchanged (one broadcast each)
+    shapes = [(3, 2, 2, 8), (5, width)]
+    keys = [torch.randint(-(1 << 31), (1 << 31) - 1, s, dtype=torch.int32, generator=g) for s in shapes]
+    got = sh.replicate_keys(keys if rank == 0 else None, shapes, root=0, like=like)
+    keys_ok = all(torch.equal(a, b) for a, b in zip(got, keys))  # same generator seed on every rank
     out = sh.bootstrap_sharded(_fake_bootstrap, full if rank == 0 else None, tv, root=0,
                                batch=batch, width=width, like=like)
+    ok = torch.tensor([int(keys_ok)])
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     if rank == 0:
-        q.put(bool(torch.equal(out, _fake_bootstrap(full, tv))))
+        q.put(bool(torch.equal(out, _fake_bootstrap(full, tv))) and bool(ok.item()))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -63,6 +63,26 @@ def gather_rows(mine, batch: int, root: int = 0):
     return full
 
 
+def replicate_keys(tensors, shapes, root: int = 0, like=None):
+    """Key upload for N ranks: the root holds the read-only tensors (BSK, KSK, test
+    vector ...), every other rank passes None and receives a copy -- one broadcast per tensor, at key
+    load time only.  `shapes` lists the tensor shapes for the ranks that have nothing yet; `like`
+    gives their dtype / device.  Returns the list of tensors on every rank."""
+    import torch
+    import torch.distributed as dist
+    rank = dist.get_rank()
+    out = []
+    for i, shape in enumerate(shapes):
+        if rank == root:
+            t = tensors[i].contiguous()
+            assert tuple(t.shape) == tuple(shape)
+        else:
+            t = torch.empty(tuple(shape), dtype=like.dtype, device=like.device)
+        dist.broadcast(t, src=root)
+        out.append(t)
+    return out
+
+
 def bootstrap_sharded(bootstrap_fn: Callable, full_lwe, tv, *, root: int = 0, batch: Optional[int] = None,
                       width: Optional[int] = None, like=None):
     """scatter -> local bootstrap_fn(lwe_shard, tv) on every rank -> gather on root."""
