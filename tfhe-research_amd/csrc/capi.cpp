@@ -251,7 +251,7 @@ hipError_t upload_twiddles(tfhe_context* ctx) {
 
 extern "C" {
 
-const char* tfhe_version(void) { return "tfhe-research_amd 0.2 (gfx950; exact NTT backends: fp64-p42, goldilocks)"; }
+const char* tfhe_version(void) { return "tfhe-research_amd 0.3 (gfx950; exact NTT backends: fp64-p42, goldilocks, goldilocks-split)"; }
 
 const char* tfhe_status_string(int status) {
   switch (status) {

@@ -1,8 +1,10 @@
 // kernels.hip -- gfx950 (CDNA4 / MI355X) kernels of the TFHE bootstrapping hot path.
 //
-// Execution shape: one workgroup = one TEAM of K+1 wavefronts = one LWE sample; wave c owns GLWE
-// polynomial c and output column c (pbs_wave.h).  Transforms are wave-local (no barrier); the
-// team meets at a workgroup barrier twice per gadget level to exchange digit spectra through LDS.
+// Execution shape: one workgroup = one TEAM of K+1 groups of G wavefronts = one LWE sample; group c
+// owns GLWE polynomial c and output column c (pbs_wave.h).  G = 1 up to N = 1024 (transforms are
+// wave-local, no barrier inside), G = 4 at N = 2048 (one cross-wave transpose per transform).  The
+// team meets at a workgroup barrier once or twice per gadget level (two or one LDS exchange
+// buffers per group) to hand the digit spectra around.
 #include "launch.h"
 
 namespace tfhe {
