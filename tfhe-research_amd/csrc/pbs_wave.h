@@ -131,8 +131,8 @@ TFHE_HD void external_product_team(const Ctx& c, const PbsParams& P, const typen
 #pragma unroll
   for (int r = 0; r < E; ++r) v[r] = round_value(src(r * T + lane), P.ignored_bits);
 
-  // Key tiles of one level for my column, in consumption order: idx = s * PARTS + q, s = source
-  // polynomial 0..K, q = part.  A tile is consumed in chunks of CH registers; chunks are staged
+  // Key tiles of one level for my column: idx = s * PARTS + q, s = source polynomial 0..K, q = part.
+  // A tile is consumed in chunks of CH registers (order: s, piece of the spectrum, q); chunks are staged
   // through two register buffers: the loads of chunk i+1 are issued before the arithmetic of chunk
   // i, and chunk 0 of a level is loaded before that level's forward transform, so no key load sits
   // on the critical path.  CH = 8 keeps the staging at 3 x 16 VGPRs whatever E is (16 measured the
@@ -187,21 +187,25 @@ TFHE_HD void external_product_team(const Ctx& c, const PbsParams& P, const typen
       for (int r = 0; r < E; ++r) mine[exchange_slot<LOGN, G>(lane, r)] = work[r];
     }
     c.team_sync();
+    // chunk order: source polynomial s, then the CH-register piece of its spectrum, then the key
+    // part q -- so that a piece of the digit spectrum is read from LDS once and used for all parts
+    elem d[CH];
     static_for<0, CHUNKS>([&](auto ci_c) {
       constexpr int ci = decltype(ci_c)::value;
-      constexpr int idx = ci / (E / CH), r0 = (ci % (E / CH)) * CH;
-      constexpr int s = idx / PARTS, q = idx % PARTS;
+      constexpr int PIECES = E / CH;
+      constexpr int q = ci % PARTS, r0 = ((ci / PARTS) % PIECES) * CH, s = ci / (PARTS * PIECES);
       constexpr int cur = ci & 1, nxt = cur ^ 1;
       if constexpr (ci + 1 < CHUNKS) {
-        constexpr int nidx = (ci + 1) / (E / CH), nr0 = ((ci + 1) % (E / CH)) * CH;
-        const elem* tile = tile_ptr(level, nidx);
+        constexpr int nq = (ci + 1) % PARTS, nr0 = (((ci + 1) / PARTS) % PIECES) * CH, ns = (ci + 1) / (PARTS * PIECES);
+        const elem* tile = tile_ptr(level, ns * PARTS + nq);
 #pragma unroll
         for (int r = 0; r < CH; ++r) kbuf[nxt][r] = tile[spectrum_slot<LOGN, G>(lane, nr0 + r)];
       }
-      const elem* spec = cl.scratch_of(s);
-      elem d[CH];
+      if constexpr (q == 0) {
+        const elem* spec = cl.scratch_of(s);
 #pragma unroll
-      for (int r = 0; r < CH; ++r) d[r] = spec[exchange_slot<LOGN, G>(lane, r0 + r)];
+        for (int r = 0; r < CH; ++r) d[r] = spec[exchange_slot<LOGN, G>(lane, r0 + r)];
+      }
       c.compiler_fence();  // keep the next chunk's loads above this chunk's arithmetic
 #pragma unroll
       for (int r = 0; r < CH; ++r)
