@@ -49,9 +49,12 @@ if "--json" in sys.argv and "FETCH_SIZE" in per and "WRITE_SIZE" in per:
         cpi = per["GRBM_GUI_ACTIVE"] / 8 * 1024 / per["SQ_INSTS_VALU"]
         valu = {"valu_insts_per_external_product": per["SQ_INSTS_VALU"] / products,
                 "cycles_per_valu_inst_per_simd": cpi,
-                "issue_floor_cycles_per_inst": 5.3,
-                "valu_issue_frac": 5.3 / cpi,
-                "floor_source": "profiles/r01_dp_chain_latency_gfx950.txt (fp64 ops, 2 waves per SIMD)"}
+                # issue cost of this kernel's mix at 2 waves per SIMD: 84 % fp64 ops at 5.3 cycles,
+                # 16 % integer ops at 4.4 (profiles/r01_dp_chain_latency_gfx950.txt,
+                # profiles/r01_valu_issue_rates_gfx950.txt; the split is DESIGN.md section 4)
+                "issue_floor_cycles_per_inst": 0.84 * 5.3 + 0.16 * 4.4,
+                "valu_issue_frac": min(1.0, (0.84 * 5.3 + 0.16 * 4.4) / cpi),
+                "floor_source": "microbenchmarks under profiles/ (fp64 5.3, integer 4.4 cycles per wave-instruction at 2 waves per SIMD)"}
     # bench.py matches on "workload" == "<name> batch <batch>": keep it to exactly that
     json.dump({"kernel": "blind_rotate_kernel<fp64-p42,10,1>", "workload": label.split(",")[0], "valu": valu,
                "fetch_size_kib": per["FETCH_SIZE"], "write_size_kib": per["WRITE_SIZE"],
