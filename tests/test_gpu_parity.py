@@ -408,3 +408,29 @@ def test_encrypted_adder_gate_graph(oracle):
         kind, lhs, rhs = circuit.gates[g]
         want = oracle.boolean_gate(p, fns[kind], wires[0, rhs], wires[0, lhs], bsk, ksk)
         assert np.array_equal(wires[0, circuit.n_inputs + g], want), g
+
+
+@pytest.mark.parametrize("cfg,samples", [("cfg2", 384), ("cfg3", 128), ("cfg1", 256), ("cfg5", 16)])
+def test_many_full_size_samples_against_the_oracle_on_all_host_cores(oracle, cfg, samples):
+    """Every BASELINE configuration with a full 4096 batch on the GPU and `samples` of its rows --
+    spread over the batch, edge rows included -- recomputed by the oracle on the host cores in
+    parallel (ctypes releases the GIL; 0.4 s (cfg1) to 30 s (cfg5) per bootstrap per core).  Every one
+    of them must match bit for bit."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    p = oracle.CONFIGS[cfg]
+    lut = np.random.default_rng(5).integers(0, 1 << p.log_p, size=1 << p.log_p) if cfg == "cfg5" else None
+    lwe, bsk, ksk, tv = oracle.synthetic_inputs(p, 4096, cfg_index=int(cfg[3:]), lut=lut)
+    lwe = lwe.copy()
+    lwe[0, 0] = 0                 # a~ = 0
+    lwe[1, p.n] = 0xFFFFFFFF      # b~ rounds to 2N and wraps
+    lwe[4095, :] = 0x80000000
+    with pkg().Context(to_pkg_params(p)) as ctx:
+        ctx.load_bootstrapping_key(bsk, ksk)
+        out = ctx.bootstrap(lwe, tv)
+    rows = sorted(set([0, 1, 4095] + list(np.random.default_rng(7).choice(4096, size=samples - 3, replace=False))))
+    workers = max(1, min(16, os.cpu_count() or 1))
+    with ThreadPoolExecutor(workers) as pool:
+        want = list(pool.map(lambda b: oracle.bootstrap(p, lwe[b], bsk, ksk, tv), rows))
+    bad = [int(b) for b, w in zip(rows, want) if not np.array_equal(out[b], w)]
+    assert not bad, f"{cfg}: rows {bad} differ from the oracle"
