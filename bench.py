@@ -206,7 +206,7 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", default="auto", choices=["auto", "goldilocks", "fp64", "goldilocks-split"])
+    ap.add_argument("--backend", default="auto", choices=["auto", "goldilocks", "fp64", "goldilocks-split", "fp64-p49"])
     ap.add_argument("--kernel", default="bootstrap", choices=["bootstrap", "external_product"],
                     help="external_product: time the standalone GGSW x GLWE kernel (ggsw.rs:132-161) instead of the PBS")
     ap.add_argument("--ggsw-per-sample", action="store_true",
@@ -257,7 +257,7 @@ def main():
     out = torch.empty_like(lwe)
 
     backend = {"auto": pkg.BACKEND_AUTO, "goldilocks": pkg.BACKEND_GOLDILOCKS, "fp64": pkg.BACKEND_FP64,
-               "goldilocks-split": pkg.BACKEND_GOLDILOCKS_SPLIT}[args.backend]
+               "goldilocks-split": pkg.BACKEND_GOLDILOCKS_SPLIT, "fp64-p49": pkg.BACKEND_FP64_P49}[args.backend]
     if args.kernel == "external_product":
         return bench_external_product(args, pkg, params, batch, dev, rand_words, world, rank, local_rank, backend)
     ctx = pkg.Context(params, device=local_rank, backend=backend)
@@ -334,7 +334,8 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f64" if backend_name.startswith("fp64") else "u64",
-        "dtype_note": ("exact NTT over the 42-bit prime 2^42-24575 in fp64" if backend_name.startswith("fp64")
+        "dtype_note": ("exact NTT over the 49-bit prime 671317819555841 in fp64" if backend_name == "fp64-p49"
+                       else "exact NTT over the 42-bit prime 2^42-24575 in fp64" if backend_name.startswith("fp64")
                        else "exact NTT over the Goldilocks prime in u64") + "; ciphertext words are wrapping u32",
         "data": "synthetic",
         "config": {

@@ -73,26 +73,31 @@ void tfhe_params_default(tfhe_params *params, int cfg_test);
 /* 0 if the reference could run this parameter set (no underflow / endless loop / shift >= 32) */
 int tfhe_params_validate(const tfhe_params *params);
 
-/* Exact-NTT backends.  Both give identical bits; they differ in speed and in the parameter sets
+/* Exact-NTT backends.  All give identical bits; they differ in speed and in the parameter sets
  * they can lift exactly (checked at context creation, TFHE_ERR_EXACTNESS otherwise):
+ *   FP64_P49   49-bit prime, fp64 arithmetic, the key word taken whole (one spectrum per key
+ *              polynomial): half the multiply-accumulate work of FP64; needs
+ *              (k+1)*l * N * B * 2^31 < 2^48.25 and (k+1)*l <= 20 -- small gadget bases, e.g. the
+ *              reference's default parameters (N = 512, k = 2, l = 6, log_base = 4)
  *   FP64       42-bit prime, fp64 arithmetic, key split into 16-bit halves; needs
  *              (k+1)*l * N * B * 2^15 < 2^40.9 and log_base <= 9
  *   GOLDILOCKS p = 2^64 - 2^32 + 1, u64 arithmetic; needs (k+1)*l * N * B * 2^32 < 2^62
  *   GOLDILOCKS_SPLIT  the same field with the key split into 16-bit halves; needs
  *              (k+1)*l * N * B * 2^15 < 2^62, which every base the reference can express satisfies
- *   AUTO       the first of FP64, GOLDILOCKS, GOLDILOCKS_SPLIT whose bound holds (env
- *              TFHE_HIP_BACKEND=fp64|goldilocks|goldilocks-split overrides AUTO). */
+ *   AUTO       the first of FP64_P49, FP64, GOLDILOCKS, GOLDILOCKS_SPLIT whose bound holds (env
+ *              TFHE_HIP_BACKEND=fp64-p49|fp64|goldilocks|goldilocks-split overrides AUTO). */
 #define TFHE_BACKEND_AUTO 0
 #define TFHE_BACKEND_GOLDILOCKS 1
 #define TFHE_BACKEND_FP64 2
 #define TFHE_BACKEND_GOLDILOCKS_SPLIT 3
+#define TFHE_BACKEND_FP64_P49 4
 
 /* Creates a context bound to HIP device `device`.  Fails with TFHE_ERR_NO_DEVICE when no GPU is
  * present: there is deliberately no CPU path behind this ABI. */
 int tfhe_context_create(const tfhe_params *params, int device, tfhe_context **out);
 int tfhe_context_create_with_backend(const tfhe_params *params, int device, int backend,
                                      tfhe_context **out);
-/* "fp64-p42", "goldilocks" or "goldilocks-split" */
+/* "fp64-p49", "fp64-p42", "goldilocks" or "goldilocks-split" */
 const char *tfhe_context_backend(const tfhe_context *ctx);
 void tfhe_context_destroy(tfhe_context *ctx);
 /* Run on an existing hipStream_t, e.g. torch.cuda.current_stream().cuda_stream.  A NULL handle is

@@ -188,18 +188,20 @@ PbsParams make_params(u32 n, u32 k, u32 log_n, u32 log_p, u32 padding, u32 log_b
   else if ((logn) == 11 && (g) == 4) { constexpr int L = 11, GG = 4; CALL; } \
   else return 1;
 
-// field: 1 = Goldilocks, 2 = fp64 prime (double elements), 3 = Goldilocks with split key; 8-byte words
+// field: 1 = Goldilocks, 2 = fp64 42-bit prime (double elements), 3 = Goldilocks with split key,
+// 4 = fp64 49-bit prime with the key word taken whole; 8-byte words
 #define DISPATCH_FIELD(field, CALL)                         \
   if ((field) == 1) { typedef GlField FF; CALL }            \
   else if ((field) == 2) { typedef FpField FF; CALL }       \
   else if ((field) == 3) { typedef GlSplitField FF; CALL }  \
+  else if ((field) == 4) { typedef Fp49Field FF; CALL }     \
   else return 3;
 
 extern "C" {
 
 void emu_set_aligned(int aligned) { g_aligned = aligned != 0; }
 void emu_set_exchange_buffers(int n) { g_exchange_buffers = n == 2 ? 2 : 1; }
-int emu_field_parts(int field) { return field == 1 ? 1 : 2; }
+int emu_field_parts(int field) { return (field == 1 || field == 4) ? 1 : 2; }
 
 int emu_poly_ntt(int field, int logn, int g, const void* in, void* out, int inverse) {
   DISPATCH_FIELD(field, DISPATCH_LOGN(logn, g, (poly_ntt<FF, L, GG>((const FF::elem*)in, (FF::elem*)out, inverse))));

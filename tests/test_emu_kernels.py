@@ -36,8 +36,24 @@ def emu():
     return lib
 
 
-GL, FP, GLS = 1, 2, 3  # Goldilocks, fp64 prime, Goldilocks with the key split in 16-bit halves
-FIELDS = [GL, FP, GLS]
+# Goldilocks, fp64 42-bit prime, Goldilocks with the key split in 16-bit halves, fp64 49-bit prime
+GL, FP, GLS, FP49 = 1, 2, 3, 4
+FIELDS = [GL, FP, GLS, FP49]
+
+
+def field_exact(field, k, logn, pbs):
+    """the bounds tfhe_context_create_with_backend checks (capi.cpp): worst-case |convolution| of
+    the (k+1)*l digit rows against the field's capacity"""
+    import math
+    rows = (k + 1) * pbs[1]
+    bits = math.log2(rows) + logn + pbs[0]
+    if field == FP:
+        return bits + 15 < 40.9 and pbs[0] <= 9
+    if field == FP49:
+        return bits + 31 < 48.25 and rows <= 20
+    if field == GL:
+        return bits + 32 < 62
+    return bits + 15 < 62
 
 
 def pd(a):
@@ -179,6 +195,13 @@ CASES = [
     (1, 11, 2, (4, 7), 2, 2),
 ]
 
+# shapes inside the 49-bit field's bounds beyond the reference default (which is in CASES)
+CASES_P49 = [
+    (1, 10, 2, (2, 10), 2, 1, 1),  # 20 digit rows, 10 stages: the field's row and growth limits
+    (2, 11, 1, (2, 5), 2, 4, 2),   # 11 stages over four waves, two exchange buffers (as shipped)
+    (1, 9, 3, (4, 6), 2, 1, 1),
+]
+
 
 @pytest.fixture(params=[1, 2], ids=["one-exchange-buffer", "two-exchange-buffers"])
 def exchange_buffers(emu, request):
@@ -191,6 +214,8 @@ def exchange_buffers(emu, request):
 @pytest.mark.parametrize("field", FIELDS)
 @pytest.mark.parametrize("k,logn,n,pbs,log_p,g", CASES)
 def test_external_product_vs_oracle(emu, oracle, exchange_buffers, field, k, logn, n, pbs, log_p, g):
+    if not field_exact(field, k, logn, pbs):
+        pytest.skip("outside this field's exactness bound")
     params = oracle.Params(k, logn, n, oracle.Decomposer(*pbs), log_p=log_p)
     rng = np.random.default_rng(11 * logn + k)
     ggsw = rng.integers(0, 1 << 32, size=(params.R, k + 1, params.N), dtype=np.uint64).astype(np.uint32)
@@ -204,7 +229,8 @@ def test_external_product_vs_oracle(emu, oracle, exchange_buffers, field, k, log
 
 
 @pytest.mark.parametrize("field", FIELDS)
-@pytest.mark.parametrize("k,logn,pbs,g", [(1, 10, (7, 3), 1), (2, 11, (8, 4), 2), (2, 11, (8, 4), 4), (2, 9, (4, 6), 1), (1, 9, (16, 2), 1)])
+@pytest.mark.parametrize("k,logn,pbs,g", [(1, 10, (7, 3), 1), (2, 11, (8, 4), 2), (2, 11, (8, 4), 4), (2, 9, (4, 6), 1), (1, 9, (16, 2), 1),
+                                          (1, 10, (2, 10), 1), (2, 11, (2, 5), 4)])
 def test_external_product_worst_case_magnitudes(emu, oracle, field, k, logn, pbs, g):
     """Adversarial inputs that drive the integer convolution to its bound: every digit at +B or
     -B/2 and every key word at 0x7FFF8000-type extremes (both 16-bit halves maximal), aligned so
@@ -212,8 +238,8 @@ def test_external_product_worst_case_magnitudes(emu, oracle, field, k, logn, pbs
     params = oracle.Params(k, logn, 1, oracle.Decomposer(*pbs))
     log_base, levels = pbs
     N = params.N
-    if field == FP and (np.log2(params.R) + logn + log_base + 15 >= 40.9 or log_base > 9):
-        pytest.skip("outside the fp64 field's exactness bound: the context selects Goldilocks here")
+    if not field_exact(field, k, logn, pbs):
+        pytest.skip("outside this field's exactness bound: the context selects another field here")
     first_shift = log_base * (32 // log_base - levels)
     # word whose every kept limb is B-1 with an incoming carry -> digits B ... (top ones), built by brute force
     def word_with_digits(target):
@@ -226,7 +252,9 @@ def test_external_product_worst_case_magnitudes(emu, oracle, field, k, logn, pbs
         return int(cand[int(score.argmax())])
     wpos = word_with_digits(+1)
     wneg = word_with_digits(-1)
-    for key_word, glwe_word in ((0x7FFF7FFF, wpos), (0x80008000, wpos), (0x7FFF8000, wneg), (0xFFFFFFFF, wneg)):
+    # 0x80000000 / 0x7FFFFFFF: the extremes of the whole signed word (the 49-bit field's key operand)
+    for key_word, glwe_word in ((0x7FFF7FFF, wpos), (0x80008000, wpos), (0x7FFF8000, wneg), (0xFFFFFFFF, wneg),
+                                (0x80000000, wpos), (0x80000000, wneg), (0x7FFFFFFF, wpos), (0x7FFFFFFF, wneg)):
         ggsw = np.full((params.R, k + 1, N), key_word, dtype=np.uint32)
         glwe = np.full((k + 1, N), glwe_word, dtype=np.uint32)
         # negacyclic sign pattern: make the key alternate sign across the wrap so sums add up at coefficient 0
@@ -240,6 +268,8 @@ def test_external_product_worst_case_magnitudes(emu, oracle, field, k, logn, pbs
 @pytest.mark.parametrize("field", FIELDS)
 @pytest.mark.parametrize("k,logn,n,pbs,log_p,g", CASES)
 def test_blind_rotate_and_extract_vs_oracle(emu, oracle, exchange_buffers, field, k, logn, n, pbs, log_p, g):
+    if not field_exact(field, k, logn, pbs):
+        pytest.skip("outside this field's exactness bound")
     params = oracle.Params(k, logn, n, oracle.Decomposer(*pbs), log_p=log_p)
     batch = 2
     lut = np.random.default_rng(5).integers(0, 1 << log_p, size=1 << log_p)
@@ -257,6 +287,31 @@ def test_blind_rotate_and_extract_vs_oracle(emu, oracle, exchange_buffers, field
         _, tr = oracle.bootstrap(params, lwe[b], bsk, ksk, tv, trace=True)
         assert np.array_equal(glwe[b], tr["acc_final"]), f"sample {b}"
         assert np.array_equal(ext[b], tr["extracted_lwe"]), f"sample {b}"
+
+
+@pytest.mark.parametrize("k,logn,n,pbs,log_p,g,exb", CASES_P49)
+def test_fp49_field_more_shapes(emu, oracle, k, logn, n, pbs, log_p, g, exb):
+    """external product and blind rotation + sample extract in the 49-bit single-spectrum field"""
+    assert field_exact(FP49, k, logn, pbs)
+    params = oracle.Params(k, logn, n, oracle.Decomposer(*pbs), log_p=log_p)
+    lwe, bsk, ksk, tv = oracle.synthetic_inputs(params, 2, cfg_index=60 + logn)
+    spec = prepared(emu, FP49, params, bsk, g)
+    emu.emu_set_exchange_buffers(exb)
+    try:
+        glwe = np.random.default_rng(logn).integers(0, 1 << 32, size=(k + 1, params.N), dtype=np.uint64).astype(np.uint32)
+        glwe[:, :4] = [0xFFFFFFFF, 0x7FFFFFFF, 0x80000000, 0xF8F8F8F8]
+        out = np.zeros_like(glwe)
+        assert emu.emu_external_product(FP49, g, k, logn, pbs[0], pbs[1], p64(spec[: params.R * (k + 1)]), p32(glwe), p32(out)) == 0
+        assert np.array_equal(out, oracle.external_product(params, bsk[0], glwe))
+        acc = np.zeros((2, k + 1, params.N), dtype=np.uint32)
+        ext = np.zeros((2, params.big_n + 1), dtype=np.uint32)
+        assert emu.emu_blind_rotate(FP49, g, n, k, logn, log_p, 1, pbs[0], pbs[1], C.c_size_t(2), p32(lwe), p32(tv),
+                                    C.c_size_t(0), p64(spec), p32(acc), p32(ext)) == 0
+    finally:
+        emu.emu_set_exchange_buffers(1)
+    for b in range(2):
+        _, tr = oracle.bootstrap(params, lwe[b], bsk, ksk, tv, trace=True)
+        assert np.array_equal(acc[b], tr["acc_final"]) and np.array_equal(ext[b], tr["extracted_lwe"])
 
 
 def test_wide_base_needs_split_goldilocks(emu, oracle):
@@ -280,6 +335,7 @@ def test_wide_base_needs_split_goldilocks(emu, oracle):
 @pytest.mark.parametrize("field", FIELDS)
 @pytest.mark.parametrize("k,logn,g", [(1, 9, 1), (2, 9, 1), (1, 10, 1), (2, 11, 1), (2, 11, 2), (2, 11, 4)])
 def test_glwe_mask_dot_key_vs_oracle(emu, oracle, field, k, logn, g):
+    # binary key x whole mask word: k N 2^31 against the field capacity (always inside for k <= 2)
     """glwe_mask_dot_key (the a*s of glwe.rs:197/:252) against the oracle's encrypt_glwe_zero /
     decrypt_glwe_ciphertext with the same pre-drawn samples; includes the all-ones key and
     all-0xFFFFFFFF / 0x8000 / 0x7FFF mask halves that maximise the convolution."""

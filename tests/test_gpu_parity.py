@@ -22,18 +22,23 @@ def make(oracle, k, logn, n, pbs, ks, log_p):
     return oracle.Params(k, logn, n, oracle.Decomposer(*pbs), oracle.Decomposer(*ks), log_p=log_p)
 
 
-BACKENDS = ["fp64", "goldilocks", "goldilocks-split"]
+BACKENDS = ["fp64", "goldilocks", "goldilocks-split", "fp64-p49"]
 
 
 def backend_id(name):
     m = pkg()
     return {"fp64": m.BACKEND_FP64, "goldilocks": m.BACKEND_GOLDILOCKS, "auto": m.BACKEND_AUTO,
-            "goldilocks-split": m.BACKEND_GOLDILOCKS_SPLIT}[name]
+            "goldilocks-split": m.BACKEND_GOLDILOCKS_SPLIT, "fp64-p49": m.BACKEND_FP64_P49}[name]
 
 
 def fp64_exact(p):
     """the fp64 backend's exactness bound (tfhe_hip.h): (k+1) l N B 2^15 < 2^40.9"""
     return np.log2(p.R) + p.glwe_poly_degree + p.pbs.log_base + 15 < 40.9 and p.pbs.log_base <= 9
+
+
+def fp49_exact(p):
+    """the 49-bit backend's bound: (k+1) l N B 2^31 < 2^48.25 and at most 20 digit rows"""
+    return np.log2(p.R) + p.glwe_poly_degree + p.pbs.log_base + 31 < 48.25 and p.R <= 20
 
 
 @pytest.fixture(scope="module")
@@ -54,6 +59,8 @@ def contexts(oracle):
             lwe[2, :] = 0x80000000
             if backend == "fp64" and not fp64_exact(p):
                 pytest.skip("outside the fp64 backend's exactness bound")
+            if backend == "fp64-p49" and not fp49_exact(p):
+                pytest.skip("outside the 49-bit backend's exactness bound")
             ctx = pkg().Context(to_pkg_params(p), backend=backend_id(backend))
             ctx.load_bootstrapping_key(bsk, ksk)
             made[key] = (p, ctx, lwe, bsk, ksk, tv)
@@ -213,6 +220,8 @@ def test_full_size_cfg2_sample_parity(oracle):
     m = pkg()
     outs = {}
     for backend in BACKENDS:
+        if backend == "fp64-p49":
+            continue  # cfg2's base 2^7 with 3 levels is outside the 49-bit field's bound (next test)
         with m.Context(to_pkg_params(p), backend=backend_id(backend)) as ctx:
             ctx.load_bootstrapping_key(bsk, ksk)
             outs[backend] = ctx.bootstrap(lwe, tv)
@@ -230,6 +239,23 @@ def test_backend_selection(oracle):
     m = pkg()
     with m.Context(to_pkg_params(oracle.CFG2)) as ctx:
         assert ctx.backend == "fp64-p42"
+    with pytest.raises(m.TfheError) as e:   # 6 * 1024 * 2^7 * 2^31 = 2^50.6 > 2^48.25
+        m.Context(to_pkg_params(oracle.CFG2), backend=m.BACKEND_FP64_P49)
+    assert e.value.status == 7
+    # the reference's default parameters (18 * 512 * 2^4 * 2^31 = 2^48.17) fit the 49-bit field: AUTO
+    # takes it, and the four fields agree bit for bit on a batch
+    p3 = oracle.CFG3
+    lwe3, bsk3, ksk3, tv3 = oracle.synthetic_inputs(p3, 32, cfg_index=3)
+    outs = {}
+    for name, b in (("auto", m.BACKEND_AUTO), ("fp64", m.BACKEND_FP64), ("gl", m.BACKEND_GOLDILOCKS),
+                    ("gls", m.BACKEND_GOLDILOCKS_SPLIT), ("p49", m.BACKEND_FP64_P49)):
+        with m.Context(to_pkg_params(p3), backend=b) as ctx:
+            if name == "auto":
+                assert ctx.backend == "fp64-p49"
+            ctx.load_bootstrapping_key(bsk3, ksk3)
+            outs[name] = ctx.bootstrap(lwe3, tv3)
+    for name in ("fp64", "gl", "gls", "p49"):
+        assert np.array_equal(outs[name], outs["auto"]), name
     wide = m.TfheParams(1, 11, 2, m.DecomposerParams(16, 2))  # 2 * 2048 * 2^16 * 2^15 = 2^43
     with m.Context(wide) as ctx:
         assert ctx.backend == "goldilocks"

@@ -251,7 +251,7 @@ hipError_t upload_twiddles(tfhe_context* ctx) {
 
 extern "C" {
 
-const char* tfhe_version(void) { return "tfhe-research_amd 0.3 (gfx950; exact NTT backends: fp64-p42, goldilocks, goldilocks-split)"; }
+const char* tfhe_version(void) { return "tfhe-research_amd 0.3 (gfx950; exact NTT backends: fp64-p49, fp64-p42, goldilocks, goldilocks-split)"; }
 
 const char* tfhe_status_string(int status) {
   switch (status) {
@@ -305,6 +305,8 @@ int tfhe_context_create_with_backend(const tfhe_params* params, int device, int 
   // (the fp64 field also relies on |digit| <= B <= 2^kSmallBits for its reduction-free first stage)
   const bool fp_ok = convolution_bits(params, FpField::key_bits()) < FpField::exact_bits() &&
                      params->pbs_decomposer.log_base <= (uint32_t)FpField::kSmallBits;
+  const bool fp49_ok = convolution_bits(params, Fp49Field::key_bits()) < Fp49Field::exact_bits() &&
+                       (params->glwe_dimension + 1) * params->pbs_decomposer.levels <= (uint32_t)Fp49Field::kMaxRows;
   const bool gl_ok = convolution_bits(params, GlField::key_bits()) < GlField::exact_bits();
   const bool gls_ok = convolution_bits(params, GlSplitField::key_bits()) < GlSplitField::exact_bits();
   int field = 0;
@@ -312,15 +314,20 @@ int tfhe_context_create_with_backend(const tfhe_params* params, int device, int 
     const char* env = std::getenv("TFHE_HIP_BACKEND");
     if (env && std::strcmp(env, "goldilocks") == 0) backend = TFHE_BACKEND_GOLDILOCKS;
     else if (env && std::strcmp(env, "fp64") == 0) backend = TFHE_BACKEND_FP64;
+    else if (env && std::strcmp(env, "fp64-p49") == 0) backend = TFHE_BACKEND_FP64_P49;
     else if (env && std::strcmp(env, "goldilocks-split") == 0) backend = TFHE_BACKEND_GOLDILOCKS_SPLIT;
   }
   if (backend == TFHE_BACKEND_AUTO)
-    field = fp_ok ? launch::kFieldFp64 : gl_ok ? launch::kFieldGoldilocks : launch::kFieldGoldilocksSplit;
+    field = fp49_ok ? launch::kFieldFp49
+            : fp_ok ? launch::kFieldFp64
+            : gl_ok ? launch::kFieldGoldilocks
+                    : launch::kFieldGoldilocksSplit;
   else if (backend == TFHE_BACKEND_GOLDILOCKS) field = launch::kFieldGoldilocks;
   else if (backend == TFHE_BACKEND_FP64) field = launch::kFieldFp64;
   else if (backend == TFHE_BACKEND_GOLDILOCKS_SPLIT) field = launch::kFieldGoldilocksSplit;
+  else if (backend == TFHE_BACKEND_FP64_P49) field = launch::kFieldFp49;
   else return TFHE_ERR_INVALID_ARGUMENT;
-  if ((field == launch::kFieldFp64 && !fp_ok) || (field == launch::kFieldGoldilocks && !gl_ok) ||
+  if ((field == launch::kFieldFp49 && !fp49_ok) || (field == launch::kFieldFp64 && !fp_ok) || (field == launch::kFieldGoldilocks && !gl_ok) ||
       (field == launch::kFieldGoldilocksSplit && !gls_ok))
     return TFHE_ERR_EXACTNESS;
   int count = 0;
@@ -362,7 +369,9 @@ int tfhe_context_create_with_backend(const tfhe_params* params, int device, int 
   ctx->own_stream = true;
   for (auto& ev : ctx->ev)
     if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e, "hipEventCreate");
-  e = field == launch::kFieldFp64 ? upload_twiddles<FpField>(ctx) : upload_twiddles<GlField>(ctx);  // both Goldilocks fields share the table
+  e = field == launch::kFieldFp64   ? upload_twiddles<FpField>(ctx)
+      : field == launch::kFieldFp49 ? upload_twiddles<Fp49Field>(ctx)
+                                    : upload_twiddles<GlField>(ctx);  // both Goldilocks fields share the table
   if (e != hipSuccess) return bail(e, "twiddle upload");
   *out = ctx;
   return TFHE_OK;
@@ -374,8 +383,10 @@ int tfhe_context_create(const tfhe_params* params, int device, tfhe_context** ou
 
 const char* tfhe_context_backend(const tfhe_context* ctx) {
   if (!ctx) return "";
-  return ctx->field == launch::kFieldFp64 ? "fp64-p42"
-         : ctx->field == launch::kFieldGoldilocks ? "goldilocks" : "goldilocks-split";
+  return ctx->field == launch::kFieldFp64     ? "fp64-p42"
+         : ctx->field == launch::kFieldFp49   ? "fp64-p49"
+         : ctx->field == launch::kFieldGoldilocks ? "goldilocks"
+                                                  : "goldilocks-split";
 }
 
 int tfhe_prepared_ggsw_words(const tfhe_context* ctx, size_t* words) {

@@ -30,6 +30,10 @@ struct FpField {
   typedef double elem;
   static constexpr int kParts = 2;
   static constexpr int kId = 2;
+  // hooks of fields with less lazy headroom (field_fp49.h); 11 bits of it here: never needed
+  static constexpr int kInverseSweepEvery = 0;
+  static constexpr bool kReduceSpectrum = false;
+  static constexpr int kMaxRows = 1 << 10;
 
   static constexpr double P = 4398046486529.0;  // 2^42 - 24575
   static constexpr double PINV = 1.0 / 4398046486529.0;

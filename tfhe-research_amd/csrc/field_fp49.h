@@ -1,0 +1,106 @@
+// field_fp49.h -- field policy: F_p with p = 671317819555841 ~ 2^49.25 (prime,
+// p - 1 = 2^15 * 5 * 1277 * 3208613, generator 3), elements are IEEE doubles holding exact integers,
+// ONE spectrum per key polynomial.
+//
+// Why: the 42-bit field (field_fp.h) needs the key split into two 16-bit halves, which doubles the
+// multiply-accumulate tiles and the inverse transforms.  Parameter sets with a small gadget base --
+// the reference's default (N = 512, k = 2, l = 6, log_base = 4: R N B 2^31 = 2^48.17) -- fit a
+// 49-bit prime with the key word taken whole (as a signed 32-bit integer).  The price is less
+// room for lazy additions (2^53 / p = 13.4), paid with a few reduction sweeps.
+//
+// Exactness (all values are integers; |twiddle|, |key spectrum| <= p/2 < 2^48.26):
+//   mul(a, w), |a| < 2^53: h = RN(a w), l = a w - h exactly (FMA); q = rint(RN(h/p)) is an integer
+//     below 2^52.1 within 1 + 2^-50|q| of h/p, so h - q p is an integer of magnitude <= 1.6 p < 2^50
+//     and the FMA returns it exactly; adding the integer l (|l| <= ulp(h)/2 <= 2^48) is exact.
+//     |mul(a, w)| <= p/2 + 2 |a| p / 2^53 (conservative).
+//   forward (Cooley-Tukey): A_{s+1} <= 1.149 A_s + p/2 from digits: 8.3 p after 9 stages, 10.1 p
+//     after 10, 12.1 p after 11 -- below 2^53 = 13.4 p.  The spectrum is reduced to |.| <= p/2 before
+//     it is published (kReduceSpectrum), so a MAC term is <= 0.58 p and R <= 20 of them stay exact.
+//   inverse (Gentleman-Sande): sums double per stage, so every element is reduced after every 4th
+//     stage (kInverseSweepEvery): p/2 -> 8 p, the operand of a multiplication (v - u) <= 8 p.
+//   lift: |t| <= R N B 2^31 < p/2 (checked when the context picks the field), so the balanced
+//     residue IS t.
+#pragma once
+#include <math.h>
+
+#include <vector>
+
+#include "platform.h"
+
+namespace tfhe {
+
+struct Fp49Field {
+  typedef double elem;
+  static constexpr int kParts = 1;
+  static constexpr int kId = 4;
+
+  static constexpr double P = 671317819555841.0;
+  static constexpr double PINV = 1.0 / 671317819555841.0;
+  static constexpr u64 P_INT = 671317819555841ull;
+
+  // hooks read by wave_ntt.h / pbs_wave.h (0 / false in the other fields)
+  static constexpr int kInverseSweepEvery = 4;
+  static constexpr bool kReduceSpectrum = true;
+  static constexpr int kMaxRows = 20;  // lazily accumulated MAC terms of <= 0.58 p each
+
+  TFHE_HD static elem zero() { return 0.0; }
+  TFHE_HD static elem add(elem a, elem b) { return a + b; }
+  TFHE_HD static elem sub(elem a, elem b) { return a - b; }
+  TFHE_HD static elem mul(elem a, elem w) {
+    const double h = a * w;
+    const double l = __builtin_fma(a, w, -h);
+    const double q = __builtin_rint(h * PINV);
+    return __builtin_fma(-q, P, h) + l;
+  }
+  // no reduction-free small stage here: 2^4 * p/2 already touches 2^53
+  static constexpr int kSmallBits = 31;
+  TFHE_HD static elem mul_small(elem a, elem w) { return mul(a, w); }
+  static constexpr bool kFuseFirstTwo = false;
+  TFHE_HD static void radix4_small(elem&, elem&, elem&, elem&, elem, elem, elem, elem, elem) {}
+  // x -> balanced residue, |x| < 2^53
+  TFHE_HD static elem reduce(elem x) { return __builtin_fma(-__builtin_rint(x * PINV), P, x); }
+  TFHE_HD static elem from_digit(u32 d) { return (double)(i32)d; }
+  // the key word as a signed 32-bit integer: w mod 2^32 with |.| <= 2^31
+  TFHE_HD static elem from_key_word(u32 w, int) { return (double)(i32)w; }
+  TFHE_HD static elem before_inverse(elem a) { return reduce(a); }
+  // exact integer t (|t| < 2^52) -> t mod 2^32
+  TFHE_HD static u32 to_u32(elem t) {
+    const double f = __builtin_floor(t * (1.0 / 4294967296.0));
+    return (u32)__builtin_fma(-4294967296.0, f, t);
+  }
+  TFHE_HD static u32 finish(const elem (&parts)[kParts]) { return to_u32(reduce(parts[0])); }
+
+  // ---- host-side constants (integer arithmetic mod p) ----
+  static inline u64 mulmod_u64(u64 a, u64 b) { return (u64)((unsigned __int128)a * b % P_INT); }
+  static inline u64 powmod_u64(u64 b, u64 e) {
+    u64 r = 1;
+    while (e) {
+      if (e & 1) r = mulmod_u64(r, b);
+      b = mulmod_u64(b, b);
+      e >>= 1;
+    }
+    return r;
+  }
+  static inline double balanced(u64 v) { return v > P_INT / 2 ? -(double)(P_INT - v) : (double)v; }
+  // out: n + 2 elements (wave_ntt.h::ntt_twiddle_words); the two extra ones are unused here
+  static inline void fill_twiddles(int logn, elem* out) {
+    const int n = 1 << logn;
+    const u64 psi = powmod_u64(3, (P_INT - 1) >> (logn + 1));  // 3 generates F_p^*
+    std::vector<u64> raw(n);
+    u64 pw = 1;
+    for (int k = 0; k < n; ++k) {
+      int rev = 0;
+      for (int b = 0; b < logn; ++b) rev |= ((k >> b) & 1) << (logn - 1 - b);
+      raw[rev] = pw;
+      out[rev] = balanced(pw);
+      pw = mulmod_u64(pw, psi);
+    }
+    out[n] = balanced(mulmod_u64(raw[1], raw[2]));
+    out[n + 1] = balanced(mulmod_u64(raw[1], raw[3]));
+  }
+  static inline elem n_inv(int logn) { return balanced(powmod_u64((u64)1 << logn, P_INT - 2)); }
+  static inline double exact_bits() { return 48.25; }  // |t| < p/2 = 2^48.254
+  static inline double key_bits() { return 31.0; }     // the whole word, signed
+};
+
+}  // namespace tfhe

@@ -13,6 +13,11 @@ struct GlFieldT {
   typedef u64 elem;
   static constexpr int kParts = PARTS;  // spectra per bootstrapping-key polynomial
   static constexpr int kId = PARTS == 1 ? 1 : 3;
+  // hooks of the lazily-reduced fp64 fields; canonical arithmetic never needs them
+  static constexpr int kInverseSweepEvery = 0;
+  static constexpr bool kReduceSpectrum = false;
+  static constexpr int kMaxRows = 1 << 20;
+  TFHE_HD static elem reduce(elem a) { return a; }
 
   TFHE_HD static elem zero() { return 0; }
   TFHE_HD static elem add(elem a, elem b) { return gl::add(a, b); }

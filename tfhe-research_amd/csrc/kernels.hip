@@ -171,8 +171,9 @@ __global__ void __launch_bounds__(256) bsk_prepare_kernel(const typename F::elem
 // ------------------------------------------------------------------------------ blind rotation
 template <class F, int LOGN, int K>
 __global__ void __launch_bounds__((TeamCfg<LOGN, K>::kThreads),
-                                  (F::kParts == 2 ? TeamCfg<LOGN, K>::kMinWavesFp
-                                                  : TeamCfg<LOGN, K>::kMinWavesGl))
+                                  (F::kId == FpField::kId || F::kId == Fp49Field::kId
+                                       ? TeamCfg<LOGN, K>::kMinWavesFp
+                                       : TeamCfg<LOGN, K>::kMinWavesGl))
 blind_rotate_kernel(PbsParams P, const typename F::elem* __restrict__ tw,
                     const u32* __restrict__ lwe_in, size_t batch, const u32* __restrict__ tv,
                     size_t tv_stride, const typename F::elem* __restrict__ bsk,
@@ -199,8 +200,9 @@ blind_rotate_kernel(PbsParams P, const typename F::elem* __restrict__ tw,
 // ------------------------------------------------------------------------------ external product
 template <class F, int LOGN, int K>
 __global__ void __launch_bounds__((TeamCfg<LOGN, K>::kThreads),
-                                  (F::kParts == 2 ? TeamCfg<LOGN, K>::kMinWavesFp
-                                                  : TeamCfg<LOGN, K>::kMinWavesGl))
+                                  (F::kId == FpField::kId || F::kId == Fp49Field::kId
+                                       ? TeamCfg<LOGN, K>::kMinWavesFp
+                                       : TeamCfg<LOGN, K>::kMinWavesGl))
 external_product_kernel(PbsParams P, const typename F::elem* __restrict__ tw,
                         const typename F::elem* __restrict__ ggsw, size_t ggsw_stride_words,
                         const u32* glwe_in, u32* ct1_inout, const u32* cmux_ct0, size_t batch,
@@ -618,7 +620,7 @@ namespace launch {
 
 bool shape_supported(u32 log_n, u32 k) { return log_n >= 9 && log_n <= 11 && (k == 1 || k == 2); }
 
-int field_parts(int field) { return field == kFieldGoldilocks ? 1 : 2; }
+int field_parts(int field) { return (field == kFieldGoldilocks || field == kFieldFp49) ? 1 : 2; }
 
 // (field, log_n, k) -> template instantiation.  TFHE_DEV_CFG2_ONLY builds just the BASELINE cfg2
 // shape (N = 1024, k = 1) for fast iteration on the kernels.
@@ -676,6 +678,9 @@ int field_parts(int field) { return field == kFieldGoldilocks ? 1 : 2; }
       BODY                                                                    \
     } else if ((field) == kFieldGoldilocksSplit) {                            \
       typedef GlSplitField FF;                                                \
+      BODY                                                                    \
+    } else if ((field) == kFieldFp49) {                                       \
+      typedef Fp49Field FF;                                                   \
       BODY                                                                    \
     }                                                                         \
     return hipErrorInvalidValue;                                              \

@@ -11,6 +11,7 @@ namespace launch {
 constexpr int kFieldGoldilocks = GlField::kId;  // 1
 constexpr int kFieldFp64 = FpField::kId;        // 2
 constexpr int kFieldGoldilocksSplit = GlSplitField::kId;  // 3
+constexpr int kFieldFp49 = Fp49Field::kId;                // 4
 
 // true if a kernel set is instantiated for (log_n, k)
 bool shape_supported(u32 log_n, u32 k);

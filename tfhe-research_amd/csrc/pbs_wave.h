@@ -180,6 +180,10 @@ TFHE_HD void external_product_team(const Ctx& c, const PbsParams& P, const typen
       // the first butterfly stage uses F::mul_small.  A team barrier precedes every level (the
       // caller's for level 0, the previous level's below) and nobody reads this buffer after it.
       ntt_forward<F, LOGN, G, true, true>(cl, work);
+      if (F::kReduceSpectrum) {  // little lazy headroom: MAC terms must start from |d| <= p/2
+#pragma unroll
+        for (int r = 0; r < E; ++r) work[r] = F::reduce(work[r]);
+      }
       // publish: element r of thread tid at exchange_slot(tid, r) -- inside my wave's own part of
       // the buffer (wave_ntt.h), conflict-free 8-byte accesses
       elem* mine = cl.scratch();
@@ -325,7 +329,7 @@ TFHE_HD void bsk_prepare_wave(const Ctx& c, const u32* poly, typename F::elem* s
     ntt_forward<F, LOGN, G>(c, x);
 #pragma unroll
     for (int r = 0; r < E; ++r)
-      spec[(size_t)part * N + spectrum_slot<LOGN, G>(lane, r)] = F::mul(x[r], n_inv);
+      spec[(size_t)part * N + spectrum_slot<LOGN, G>(lane, r)] = F::reduce(F::mul(x[r], n_inv));
   }
 }
 
@@ -360,7 +364,7 @@ TFHE_HD void glwe_mask_dot_key(const Ctx& c, u32 k, const u32* masks /* [k][N] *
     for (int r = 0; r < E; ++r) s[r] = F::from_digit(sk[(size_t)i * N + r * T + lane]);
     ntt_forward<F, LOGN, G, true>(c, s);
 #pragma unroll
-    for (int r = 0; r < E; ++r) s[r] = F::mul(s[r], n_inv);
+    for (int r = 0; r < E; ++r) s[r] = F::reduce(F::mul(s[r], n_inv));
     static_for<0, PARTS>([&](auto part_c) {
       constexpr int q = decltype(part_c)::value;
       elem x[E];
@@ -368,7 +372,8 @@ TFHE_HD void glwe_mask_dot_key(const Ctx& c, u32 k, const u32* masks /* [k][N] *
       for (int r = 0; r < E; ++r) x[r] = F::from_key_word(masks[(size_t)i * N + r * T + lane], q);
       ntt_forward<F, LOGN, G>(c, x);
 #pragma unroll
-      for (int r = 0; r < E; ++r) accum[q][r] = F::add(accum[q][r], F::mul(x[r], s[r]));
+      for (int r = 0; r < E; ++r)
+        accum[q][r] = F::add(accum[q][r], F::mul(F::kReduceSpectrum ? F::reduce(x[r]) : x[r], s[r]));
     });
   }
 

@@ -37,6 +37,7 @@
 // and Ctx with_exchange_buffer(int i) const (a copy whose scratch()/scratch_of() use buffer i).
 #pragma once
 #include "field_fp.h"
+#include "field_fp49.h"
 #include "field_gl.h"
 
 namespace tfhe {
@@ -203,6 +204,14 @@ TFHE_HD void ntt_pass_inverse(const Ctx& c, typename F::elem (&x)[NttShape<LOGN,
       const elem v = x[r1];
       x[r0] = F::add(u, v);
       x[r1] = F::mul(F::sub(v, u), w);
+    }
+    // fields with little lazy headroom (F::kInverseSweepEvery > 0): the un-multiplied leg doubles
+    // per stage, so everything is brought back to |.| <= p/2 after every kInverseSweepEvery-th stage
+    // (stage number = b + 1; nothing to do after the last one, finish() reduces)
+    if (F::kInverseSweepEvery > 0 && (b + 1) % (F::kInverseSweepEvery > 0 ? F::kInverseSweepEvery : 1) == 0 &&
+        b + 1 < LOGN) {
+#pragma unroll
+      for (int r = 0; r < E; ++r) x[r] = F::reduce(x[r]);
     }
   }
 }
