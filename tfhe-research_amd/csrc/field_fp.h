@@ -33,6 +33,9 @@ struct FpField {
   // hooks of fields with less lazy headroom (field_fp49.h); 11 bits of it here: never needed
   static constexpr int kInverseSweepEvery = 0;
   static constexpr bool kReduceSpectrum = false;
+  static constexpr bool kSplitAccum = false;  // field_fp49.h: (h, l) accumulator pairs
+  TFHE_HD static void mac(elem, elem, elem&, elem&) {}
+  TFHE_HD static elem mac_finish(elem a, elem) { return a; }
   static constexpr int kMaxRows = 1 << 10;
 
   static constexpr double P = 4398046486529.0;  // 2^42 - 24575

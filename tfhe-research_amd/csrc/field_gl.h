@@ -16,6 +16,9 @@ struct GlFieldT {
   // hooks of the lazily-reduced fp64 fields; canonical arithmetic never needs them
   static constexpr int kInverseSweepEvery = 0;
   static constexpr bool kReduceSpectrum = false;
+  static constexpr bool kSplitAccum = false;  // field_fp49.h: (h, l) accumulator pairs
+  TFHE_HD static void mac(elem, elem, elem&, elem&) {}
+  TFHE_HD static elem mac_finish(elem a, elem) { return a; }
   static constexpr int kMaxRows = 1 << 20;
   TFHE_HD static elem reduce(elem a) { return a; }
 

@@ -119,10 +119,15 @@ TFHE_HD void external_product_team(const Ctx& c, const PbsParams& P, const typen
   const int me = c.group();   // polynomial / output column owned by my group
 
   elem accum[PARTS][E];
+  // second accumulator set of fields that add up unreduced (h, l) product pairs (F::kSplitAccum)
+  elem accum_lo[F::kSplitAccum ? PARTS : 1][F::kSplitAccum ? E : 1];
 #pragma unroll
   for (int q = 0; q < PARTS; ++q)
 #pragma unroll
-    for (int r = 0; r < E; ++r) accum[q][r] = F::zero();
+    for (int r = 0; r < E; ++r) {
+      accum[q][r] = F::zero();
+      if (F::kSplitAccum) accum_lo[F::kSplitAccum ? q : 0][F::kSplitAccum ? r : 0] = F::zero();
+    }
 
   // v[r]: rounded coefficient.  The running carry of the digit chain lives in bit 0 of v[r]: the
   // lowest kept limb is extracted first (its carry-in is 0 by construction), after that bit 0 is
@@ -212,8 +217,12 @@ TFHE_HD void external_product_team(const Ctx& c, const PbsParams& P, const typen
       }
       c.compiler_fence();  // keep the next chunk's loads above this chunk's arithmetic
 #pragma unroll
-      for (int r = 0; r < CH; ++r)
-        accum[q][r0 + r] = F::add(accum[q][r0 + r], F::mul(d[r], kbuf[cur][r]));
+      for (int r = 0; r < CH; ++r) {
+        if (F::kSplitAccum)
+          F::mac(d[r], kbuf[cur][r], accum[q][r0 + r], accum_lo[F::kSplitAccum ? q : 0][F::kSplitAccum ? r0 + r : 0]);
+        else
+          accum[q][r0 + r] = F::add(accum[q][r0 + r], F::mul(d[r], kbuf[cur][r]));
+      }
     });
     if (!two) c.team_sync();  // everyone is done reading before the next transform reuses the buffer
   }
@@ -222,7 +231,9 @@ TFHE_HD void external_product_team(const Ctx& c, const PbsParams& P, const typen
   static_for<0, PARTS>([&](auto part_c) {
     constexpr int q = decltype(part_c)::value;
 #pragma unroll
-    for (int r = 0; r < E; ++r) accum[q][r] = F::before_inverse(accum[q][r]);
+    for (int r = 0; r < E; ++r)
+      accum[q][r] = F::kSplitAccum ? F::mac_finish(accum[q][r], accum_lo[F::kSplitAccum ? q : 0][F::kSplitAccum ? r : 0])
+                                   : F::before_inverse(accum[q][r]);
     ntt_inverse<F, LOGN, G>(ci, accum[q]);
   });
 #pragma unroll
