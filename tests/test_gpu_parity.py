@@ -460,3 +460,28 @@ def test_many_full_size_samples_against_the_oracle_on_all_host_cores(oracle, cfg
         want = list(pool.map(lambda b: oracle.bootstrap(p, lwe[b], bsk, ksk, tv), rows))
     bad = [int(b) for b, w in zip(rows, want) if not np.array_equal(out[b], w)]
     assert not bad, f"{cfg}: rows {bad} differ from the oracle"
+
+
+def test_fields_agree_on_a_large_cfg3_batch(oracle):
+    """Independent arithmetic, same bits: 16,384 random full-size cfg3 bootstraps in the 49-bit
+    single-spectrum field (AUTO) against the 42-bit split-key field, and the first 2,048 of them
+    against Goldilocks -- every output word equal."""
+    import torch
+    p = oracle.CFG3
+    m = pkg()
+    _, bsk, ksk, tv = oracle.synthetic_inputs(p, 1, cfg_index=3)
+    gen = torch.Generator(device="cuda:0").manual_seed(99)
+    lwe = torch.randint(-(1 << 31), (1 << 31) - 1, (16384, p.n + 1), dtype=torch.int32, device="cuda:0", generator=gen)
+    tv_d = torch.from_numpy(tv.view(np.int32)).to("cuda:0")
+    outs = {}
+    for name, b, count in (("p49", m.BACKEND_AUTO, 16384), ("p42", m.BACKEND_FP64, 16384), ("gl", m.BACKEND_GOLDILOCKS, 2048)):
+        with m.Context(to_pkg_params(p), backend=b) as ctx:
+            if name == "p49":
+                assert ctx.backend == "fp64-p49"
+            ctx.load_bootstrapping_key(bsk, ksk)
+            ctx.use_torch_stream()
+            outs[name] = ctx.bootstrap(lwe[:count].contiguous(), tv_d)
+            torch.cuda.synchronize()
+            ctx.set_stream(None)
+    assert torch.equal(outs["p49"], outs["p42"])
+    assert torch.equal(outs["p49"][:2048], outs["gl"])
