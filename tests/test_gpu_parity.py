@@ -462,26 +462,32 @@ def test_many_full_size_samples_against_the_oracle_on_all_host_cores(oracle, cfg
     assert not bad, f"{cfg}: rows {bad} differ from the oracle"
 
 
-def test_fields_agree_on_a_large_cfg3_batch(oracle):
-    """Independent arithmetic, same bits: 16,384 random full-size cfg3 bootstraps in the 49-bit
-    single-spectrum field (AUTO) against the 42-bit split-key field, and the first 2,048 of them
-    against Goldilocks -- every output word equal."""
+@pytest.mark.parametrize("cfg,fast,count,slow_count", [("cfg3", "fp64-p49", 16384, 2048), ("cfg2", "fp64-p42", 8192, 2048),
+                                                       ("cfg5", "fp64-p42", 1024, 256), ("cfg1", "fp64-p42", 8192, 2048)])
+def test_fields_agree_on_large_batches(oracle, cfg, fast, count, slow_count):
+    """Independent arithmetic, same bits: `count` random full-size bootstraps in the field AUTO
+    picks against the other fp64 field where it is exact, and the first `slow_count` of them against
+    Goldilocks and Goldilocks-split -- every output word equal."""
     import torch
-    p = oracle.CFG3
+    p = oracle.CONFIGS[cfg]
     m = pkg()
-    _, bsk, ksk, tv = oracle.synthetic_inputs(p, 1, cfg_index=3)
+    lut = np.random.default_rng(5).integers(0, 1 << p.log_p, size=1 << p.log_p)
+    _, bsk, ksk, tv = oracle.synthetic_inputs(p, 1, cfg_index=int(cfg[3:]), lut=lut)
     gen = torch.Generator(device="cuda:0").manual_seed(99)
-    lwe = torch.randint(-(1 << 31), (1 << 31) - 1, (16384, p.n + 1), dtype=torch.int32, device="cuda:0", generator=gen)
+    lwe = torch.randint(-(1 << 31), (1 << 31) - 1, (count, p.n + 1), dtype=torch.int32, device="cuda:0", generator=gen)
     tv_d = torch.from_numpy(tv.view(np.int32)).to("cuda:0")
+    runs = [("auto", m.BACKEND_AUTO, count), ("gl", m.BACKEND_GOLDILOCKS, slow_count), ("gls", m.BACKEND_GOLDILOCKS_SPLIT, slow_count)]
+    if fast == "fp64-p49":
+        runs.append(("p42", m.BACKEND_FP64, count))
     outs = {}
-    for name, b, count in (("p49", m.BACKEND_AUTO, 16384), ("p42", m.BACKEND_FP64, 16384), ("gl", m.BACKEND_GOLDILOCKS, 2048)):
+    for name, b, c in runs:
         with m.Context(to_pkg_params(p), backend=b) as ctx:
-            if name == "p49":
-                assert ctx.backend == "fp64-p49"
+            if name == "auto":
+                assert ctx.backend == fast
             ctx.load_bootstrapping_key(bsk, ksk)
             ctx.use_torch_stream()
-            outs[name] = ctx.bootstrap(lwe[:count].contiguous(), tv_d)
+            outs[name] = ctx.bootstrap(lwe[:c].contiguous(), tv_d)
             torch.cuda.synchronize()
             ctx.set_stream(None)
-    assert torch.equal(outs["p49"], outs["p42"])
-    assert torch.equal(outs["p49"][:2048], outs["gl"])
+    for name, _, c in runs[1:]:
+        assert torch.equal(outs["auto"][:c], outs[name]), name
