@@ -155,3 +155,27 @@ def test_full_scale_keygen_encrypt_bootstrap_decrypt(oracle, cfg, valid_crypto):
         shift = 32 - p.log_p - p.padding_bits
         decoded = ((dec.astype(np.uint64) + (1 << (shift - 1))) >> shift) & ((1 << p.log_p) - 1)
         assert np.array_equal(decoded.astype(np.uint32), msgs)
+
+
+def test_convenience_keygen_encrypt_gate_decrypt(oracle):
+    """Context.generate_keys / encrypt_bits / decrypt_bits: the whole client + server flow of the
+    reference's boolean_gates_work (boolean.rs:67-101) at its default parameters through the package
+    alone -- no oracle involved in producing keys or ciphertexts, only in the final spot check."""
+    m = pkg()
+    p = oracle.REF_DEFAULT
+    rng = np.random.default_rng(4)
+    with m.Context(to_pkg_params(p)) as ctx:
+        lwe_sk, glwe_sk, bsk, ksk = ctx.generate_keys(rng)
+        a = rng.integers(0, 2, size=512).astype(np.uint32)
+        b = rng.integers(0, 2, size=512).astype(np.uint32)
+        ca, cb = ctx.encrypt_bits(lwe_sk, a, rng), ctx.encrypt_bits(lwe_sk, b, rng)
+        assert np.array_equal(ctx.decrypt_bits(lwe_sk, ca), a)
+        nand = ctx.gate(m.GATE_NAND, cb, ca)       # truth[(lhs << 1) | rhs], lhs = ct1
+        xor = ctx.gate(m.GATE_XOR, cb, ca)
+        assert np.array_equal(ctx.decrypt_bits(lwe_sk, nand), 1 - (a & b))
+        assert np.array_equal(ctx.decrypt_bits(lwe_sk, xor), a ^ b)
+        assert np.array_equal(ctx.decrypt_bits(lwe_sk, ctx.lwe_not(nand)), a & b)
+    assert np.array_equal(nand[7], oracle.boolean_gate(p, lambda l, r: 1 - (l & r), cb[7], ca[7], bsk, ksk))
+    with pytest.raises(m.TfheError):
+        with m.Context(to_pkg_params(oracle.REF_TEST)) as ctx:
+            ctx.encrypt_bits(np.zeros(4, dtype=np.uint32), [5])

@@ -74,6 +74,9 @@ class TfheParams:
     log_p: int = 2
     padding_bits: int = 1
     log_q: int = 32
+    # noise parameters (lib.rs:96-97,120-121); only key generation / encryption helpers read them
+    lwe_std_dev: float = 0.000013071021089943935
+    glwe_std_dev: float = 0.00000004990272175010415
 
     @property
     def N(self) -> int:
@@ -688,3 +691,45 @@ class Context:
         self._check(lib().tfhe_bootstrapping_key_gen(self._h, _hp(lsk), _hp(gsk), _hp(bsk), _hp(ksk),
                                                      C.c_int(int(load))))
         return bsk, ksk
+
+    # -- convenience on top of the encryption-side entry points ---------------------------------
+    @staticmethod
+    def _noise(rng, std_dev: float, shape) -> np.ndarray:
+        """two-sided rounded Gaussian on the 32-bit torus (utils.rs:36-54 without the saturation)"""
+        return (np.rint(rng.normal(0.0, std_dev * 2.0 ** 32, size=shape)).astype(np.int64) & 0xFFFFFFFF).astype(np.uint32)
+
+    def generate_keys(self, rng=None, load: bool = True):
+        """LweSecretKey::random + GlweSecretKey::random + bootstrapping_key_gen (lwe.rs:53-60,
+        glwe.rs:176-182, bootstrapping.rs:23-56): secrets, masks and errors are drawn here with a
+        numpy Generator (the reference draws them with its rng), the key material is completed on
+        the GPU and, with `load`, installed.  -> (lwe_sk [n], glwe_sk [k][N], bsk, ksk)"""
+        p = self.params
+        rng = rng if rng is not None else np.random.default_rng()
+        lwe_sk = rng.integers(0, 2, size=p.n).astype(np.uint32)
+        glwe_sk = rng.integers(0, 2, size=(p.k, p.N)).astype(np.uint32)
+        bsk = rng.integers(0, 1 << 32, size=p.bsk_shape(), dtype=np.uint64).astype(np.uint32)
+        bsk[:, :, p.k, :] = self._noise(rng, p.glwe_std_dev, (p.n, p.R, p.N))
+        ksk = rng.integers(0, 1 << 32, size=p.ksk_shape(), dtype=np.uint64).astype(np.uint32)
+        ksk[:, p.n] = self._noise(rng, p.lwe_std_dev, ksk.shape[0])
+        bsk, ksk = self.bootstrapping_key_gen(lwe_sk, glwe_sk, bsk, ksk, load=load)
+        return lwe_sk, glwe_sk, bsk, ksk
+
+    def encrypt_bits(self, lwe_sk, messages, rng=None) -> np.ndarray:
+        """LweCleartext::encode_message + encrypt_lwe_plaintext (lwe.rs:81-92,138-160) for a batch
+        of messages < 2^log_p under `lwe_sk` (any dimension) -> [batch][dim+1]"""
+        p = self.params
+        rng = rng if rng is not None else np.random.default_rng()
+        msg = np.asarray(messages, dtype=np.uint32).reshape(-1)
+        if msg.size and int(msg.max()) >> p.log_p:
+            raise TfheError(TFHE_ERR_INVALID_ARGUMENT, "assertion failed: m < 1 << log_p (lwe.rs:84)")
+        sk = _np(lwe_sk).reshape(-1)
+        samples = rng.integers(0, 1 << 32, size=(msg.size, sk.size + 1), dtype=np.uint64).astype(np.uint32)
+        samples[:, sk.size] = self._noise(rng, p.lwe_std_dev, msg.size)
+        return self.lwe_encrypt(sk, samples, (msg << (32 - p.log_p - p.padding_bits)).astype(np.uint32))
+
+    def decrypt_bits(self, lwe_sk, lwe) -> np.ndarray:
+        """decrypt_lwe + rounding to the nearest message slot (lwe.rs:162-173, :100-107)"""
+        p = self.params
+        shift = 32 - p.log_p - p.padding_bits
+        raw = self.lwe_decrypt(lwe_sk, lwe).astype(np.uint64)
+        return (((raw + (1 << (shift - 1))) >> shift) & ((1 << p.log_p) - 1)).astype(np.uint32)
