@@ -3,7 +3,7 @@
 // through bsk_prepare, external product, blind rotation + sample extract and the keygen wave
 // function for every shipped shape, in both exchange-buffer schemes.  LDS buffers are exact-size
 // heap vectors in the emulator, so an out-of-range slot, swizzle or twiddle index trips ASan.
-//   g++ -O1 -g -std=c++17 -ffp-contract=off -fsanitize=address,undefined -fno-sanitize-recover=all
+//   g++ -O1 [-g] -std=c++17 -ffp-contract=off -fsanitize=address,undefined -fno-sanitize-recover=all
 //       -pthread -I tfhe-research_amd/csrc tests/emu/sanitize_main.cpp -o tests/emu/sanitize && tests/emu/sanitize
 #include "emu.cpp"
 

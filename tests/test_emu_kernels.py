@@ -380,7 +380,7 @@ def test_device_headers_under_address_and_ub_sanitizers():
     src = os.path.join(EMU_DIR, "sanitize_main.cpp")
     deps = [src, os.path.join(EMU_DIR, "emu.cpp")] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     if not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps):
-        subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fsanitize=address,undefined",
+        subprocess.run(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-fsanitize=address,undefined",  # add -g to localise a report
                         "-fno-sanitize-recover=all", "-pthread", "-I", CSRC, src, "-o", exe], check=True)
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
     res = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=900)
