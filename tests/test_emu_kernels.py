@@ -137,8 +137,8 @@ def test_fp_field_arithmetic(emu):
     red = np.zeros(n)
     emu.emu_fp_reduce_many(pd(a), pd(red), C.c_size_t(n))
     assert all((int(r) - x) % p == 0 and abs(int(r)) <= p // 2 + 1 for r, x in zip(red, ai))
-    t = rng.integers(-(1 << 52), 1 << 52, size=n).astype(np.float64)
-    t[:6] = [0, -1, (1 << 32), -(1 << 32), (1 << 32) - 1, -(1 << 31)]
+    t = rng.integers(-(1 << 51) + 1, 1 << 51, size=n).astype(np.float64)   # to_u32's domain: |t| < 2^51
+    t[:8] = [0, -1, (1 << 32), -(1 << 32), (1 << 32) - 1, -(1 << 31), (1 << 51) - 1, -(1 << 51) + 1]
     u = np.zeros(n, dtype=np.uint32)
     emu.emu_fp_to_u32_many(pd(t), p32(u), C.c_size_t(n))
     assert u.tolist() == [int(x) % (1 << 32) for x in t]

@@ -86,10 +86,14 @@ struct FpField {
     return (double)((i32)(w - (u32)lo) >> 16);
   }
   TFHE_HD static elem before_inverse(elem a) { return reduce(a); }
-  // exact integer t (|t| < 2^52) -> t mod 2^32
+  // exact integer t (|t| < 2^51) -> t mod 2^32: t + 1.5 * 2^52 lies in [2^52, 2^53), where doubles
+  // are the integers, so the sum is exact and its 52 mantissa bits hold 2^51 + t; their low 32
+  // bits are t mod 2^32 (two's complement for negative t).  One add instead of mul, floor, fma, cvt.
   TFHE_HD static u32 to_u32(elem t) {
-    const double f = __builtin_floor(t * (1.0 / 4294967296.0));
-    return (u32)__builtin_fma(-4294967296.0, f, t);
+    const double shifted = t + 6755399441055744.0;  // 1.5 * 2^52
+    u64 bits;
+    __builtin_memcpy(&bits, &shifted, sizeof(bits));
+    return (u32)bits;
   }
   TFHE_HD static u32 finish(const elem (&parts)[kParts]) {
     return to_u32(reduce(parts[0])) + (to_u32(reduce(parts[1])) << 16);
