@@ -90,19 +90,26 @@ WORKLOADS = {
     "cfg2": (1, 10, 630, (7, 3), (4, 5), 2, 4096),
     "cfg3": (2, 9, 722, (4, 6), (4, 5), 2, 4096),
     "cfg1": (1, 9, 500, (8, 2), (4, 5), 2, 4096),
-    "cfg5": (2, 11, 630, (8, 4), (4, 5), 4, 512),
+    "cfg5": (2, 11, 630, (8, 4), (4, 5), 4, 4096),
+    # BASELINE configs[3]: batch 2^20 sharded over 8 GPUs = 2^17 ciphertexts per GPU, cfg2 parameters
+    "cfg4": (1, 10, 630, (7, 3), (4, 5), 2, 1 << 17),
 }
+CPU_BASELINE_PBS = 3        # >= 3 PBS on one thread (the reference is single-threaded)
+CPU_BASELINE_THREADS = 16   # the all-cores leg: one round of independent ciphertexts, capped
 
 
 def cpu_baseline(workload: str, budget_s: float):
     """Time the oracle's literal path (Toeplitz matrix + mat-vec, as the reference does) on a bounded
-    sample: whole bootstraps of the same parameter set, single thread (the reference is
-    single-threaded)."""
+    sample: CPU_BASELINE_PBS whole bootstraps of the same parameter set on a single thread (the
+    reference is single-threaded), stopping early once `budget_s` is spent; then one round of
+    independent ciphertexts on up to CPU_BASELINE_THREADS host threads.  Kept short on purpose: the
+    GPU part of a default run is a second or two, and a CPU leg of half a minute would be nearly
+    all the driver's activity sampler ever sees."""
     from oracle import oracle as orc
     orc.build()
     k, logn, n, pbs, ks, log_p, _ = WORKLOADS[workload]
     p = orc.Params(k, logn, n, orc.Decomposer(*pbs), orc.Decomposer(*ks), log_p=log_p)
-    lwe, bsk, ksk, tv = orc.synthetic_inputs(p, 8, cfg_index=2)
+    lwe, bsk, ksk, tv = orc.synthetic_inputs(p, CPU_BASELINE_PBS, cfg_index=2)
     orc.set_poly_mul_mode(0)
     done, t0 = 0, time.perf_counter()
     while done < lwe.shape[0]:
@@ -116,9 +123,9 @@ def cpu_baseline(workload: str, budget_s: float):
         "sample": f"{done} full bootstraps of {workload} (literal Toeplitz path, gcc -O2, 1 thread) in {dt:.1f} s",
         "host_cores_available": os.cpu_count(),
     }
-    # the same port on many host cores (independent ciphertexts, one per thread; ctypes releases the
-    # GIL): the fair throughput comparison, reported beside the single-thread number, not instead
-    threads = min(os.cpu_count() or 1, 64)
+    # the same port on several host cores (independent ciphertexts, one per thread; ctypes releases
+    # the GIL): the fair throughput comparison, reported beside the single-thread number, not instead
+    threads = min(os.cpu_count() or 1, CPU_BASELINE_THREADS)
     if threads > 1 and budget_s > 0:
         from concurrent.futures import ThreadPoolExecutor
         lwe_many = np.tile(lwe, (threads // lwe.shape[0] + 1, 1))[:threads]
@@ -204,7 +211,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=0, help="ciphertexts per GPU per step (default: workload's)")
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0,
+                    help="time budget of the single-thread CPU leg (it stops after CPU_BASELINE_PBS bootstraps anyway)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="auto", choices=["auto", "goldilocks", "fp64", "goldilocks-split", "fp64-p49"])
     ap.add_argument("--kernel", default="bootstrap", choices=["bootstrap", "external_product"],
@@ -251,10 +259,25 @@ def main():
         return torch.randint(-(1 << 31), (1 << 31) - 1, shape, dtype=torch.int32, device=dev, generator=gen)
 
     lwe = rand_words(batch, n + 1)
-    bsk = rand_words(*params.bsk_shape())
-    ksk = rand_words(*params.ksk_shape())
     tv = torch.from_numpy(pkg.construct_identity_test_vector(params).astype(np.int32)).to(dev)
     out = torch.empty_like(lwe)
+    key_replication = "one GPU"
+    if use_dist and world > 1 and args.kernel == "bootstrap":
+        # the read-only keys exist once (on rank 0, like a BootstrappingKey the host
+        # uploaded there, bootstrapping.rs:18-21) and are REPLICATED to every GPU with one RCCL
+        # broadcast per tensor at key-load time; nothing else of the path ever crosses ranks
+        import importlib
+        sharding = importlib.import_module("tfhe_research_amd.sharding")
+        t_rep = time.perf_counter()
+        held = [rand_words(*params.bsk_shape()), rand_words(*params.ksk_shape())] if rank == 0 else None
+        bsk, ksk = sharding.replicate_keys(held, [params.bsk_shape(), params.ksk_shape()], root=0, like=lwe)
+        torch.cuda.synchronize()
+        del held
+        key_replication = (f"BSK+KSK drawn on rank 0 and broadcast over RCCL to {world} ranks "
+                           f"({(bsk.numel() + ksk.numel()) * 4 / 1e6:.0f} MB, {time.perf_counter() - t_rep:.2f} s incl. generation)")
+    else:
+        bsk = rand_words(*params.bsk_shape())
+        ksk = rand_words(*params.ksk_shape())
 
     backend = {"auto": pkg.BACKEND_AUTO, "goldilocks": pkg.BACKEND_GOLDILOCKS, "fp64": pkg.BACKEND_FP64,
                "goldilocks-split": pkg.BACKEND_GOLDILOCKS_SPLIT, "fp64-p49": pkg.BACKEND_FP64_P49}[args.backend]
@@ -342,8 +365,8 @@ def main():
             "workload": f"{args.workload}: batch {batch}/GPU, N={1 << logn}, k={k}, n={n}, l={pbs[1]}, log2B={pbs[0]}, "
                         f"KS l={ks[1]} log2B={ks[0]}, log_p={log_p}, " + (f"{args.gate.upper()} gate stream" if args.gate else "identity LUT"),
             "global_batch": batch * world,
-            "parallelism": f"dp{world} (independent LWE shards, keys replicated"
-                           + (", batch scattered from / gathered to rank 0 over RCCL every step)" if args.scatter_gather else ")"),
+            "parallelism": f"dp{world} (independent LWE shards resident per GPU, no data-path collective; keys: {key_replication}"
+                           + ("; batch scattered from / gathered to rank 0 over RCCL every step)" if args.scatter_gather else ")"),
         },
         "roofline": {
             "kernel": kernel_name,
@@ -364,6 +387,30 @@ def main():
             "note": "VALU-issue bound by design (SURVEY 8d): the key is shared by the batch and stays in L2/Infinity Cache; HBM fraction reported as the metric asks",
         },
     }
+    if use_dist and world > 1 and not args.scatter_gather and not args.gate:
+        # second figure, outside the timed region above: the same step with rank 0 owning the whole
+        # batch -- RCCL scatter of [B/N][n+1] rows, local bootstrap, gather (sharding.bootstrap_sharded)
+        import importlib
+        sharding = importlib.import_module("tfhe_research_amd.sharding")
+        full = rand_words(batch * world, n + 1) if rank == 0 else None
+
+        def sg_step():
+            sharding.bootstrap_sharded(lambda shard, tvv: ctx.bootstrap(shard, tvv), full, tv, root=0,
+                                       batch=batch * world, width=n + 1, like=lwe)
+        sg_step()
+        barrier()
+        sg_steps = max(2, min(args.steps, 5))
+        t1 = time.perf_counter()
+        for _ in range(sg_steps):
+            sg_step()
+        barrier()
+        t_sg = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        dist.all_reduce(t_sg, op=dist.ReduceOp.MAX)
+        result["scatter_gather"] = {
+            "value": batch * world * sg_steps / float(t_sg.item()), "unit": "PBS/s", "steps": sg_steps,
+            "ms_per_step": float(t_sg.item()) / sg_steps * 1e3,
+            "what": f"rank 0 holds all {batch * world} ciphertexts: isend/recv scatter of {batch * (n + 1) * 4 / 1e6:.0f} MB per peer "
+                    "over RCCL/xGMI, local bootstrap, gather back; NOT the headline value"}
     ctx.close()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_baseline_seconds)

@@ -306,6 +306,7 @@ int tfhe_context_set_decomposer_alignment(tfhe_context *ctx, int aligned);
 #define TFHE_FILE_LWE 3   /* [batch][dim+1] */
 #define TFHE_FILE_GLWE 4  /* [batch][k+1][N] */
 #define TFHE_FILE_GGSW 5  /* [count][(k+1)l][k+1][N] */
+#define TFHE_FILE_WORDS 6 /* any other u32 array (test vectors [N], mod-switched masks, ...) */
 #define TFHE_FILE_FLAG_ALIGNED 1u
 int tfhe_file_write(const char *path, uint32_t kind, const tfhe_params *params, uint32_t flags,
                     const uint32_t *dims, uint32_t ndims, const uint32_t *data);

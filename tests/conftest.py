@@ -1,4 +1,6 @@
+import ctypes as C
 import os
+import subprocess
 import sys
 
 import pytest
@@ -19,3 +21,26 @@ def oracle():
     orc.build()
     orc.set_poly_mul_mode(1)
     return orc
+
+
+EMU_DIR = os.path.join(ROOT, "tests", "emu")
+CSRC = os.path.join(ROOT, "tfhe-research_amd", "csrc")
+
+
+@pytest.fixture(scope="session")
+def emu():
+    """The host SIMT emulator: the device headers (csrc/*.h) compiled by g++ (tests/emu/emu.cpp)."""
+    so = os.path.join(EMU_DIR, "libtfhe_emu.so")
+    srcs = [os.path.join(EMU_DIR, "emu.cpp")] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread", "-I", CSRC,
+                        "-o", so, os.path.join(EMU_DIR, "emu.cpp")], check=True)
+    lib = C.CDLL(so)
+    for f in ("emu_gl_mul", "emu_gl_add", "emu_gl_sub", "emu_gl_from_i32"):
+        getattr(lib, f).restype = C.c_uint64
+    lib.emu_gl_lift.restype = C.c_uint32
+    lib.emu_fp_p.restype = C.c_double
+    lib.emu_fp_from_key_word.restype = C.c_double
+    return lib
+
+

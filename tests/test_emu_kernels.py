@@ -20,22 +20,6 @@ EMU_DIR = os.path.join(HERE, "emu")
 CSRC = os.path.join(ROOT, "tfhe-research_amd", "csrc")
 
 
-@pytest.fixture(scope="session")
-def emu():
-    so = os.path.join(EMU_DIR, "libtfhe_emu.so")
-    srcs = [os.path.join(EMU_DIR, "emu.cpp")] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread", "-I", CSRC,
-                        "-o", so, os.path.join(EMU_DIR, "emu.cpp")], check=True)
-    lib = C.CDLL(so)
-    for f in ("emu_gl_mul", "emu_gl_add", "emu_gl_sub", "emu_gl_from_i32"):
-        getattr(lib, f).restype = C.c_uint64
-    lib.emu_gl_lift.restype = C.c_uint32
-    lib.emu_fp_p.restype = C.c_double
-    lib.emu_fp_from_key_word.restype = C.c_double
-    return lib
-
-
 # Goldilocks, fp64 42-bit prime, Goldilocks with the key split in 16-bit halves, fp64 49-bit prime
 GL, FP, GLS, FP49 = 1, 2, 3, 4
 FIELDS = [GL, FP, GLS, FP49]

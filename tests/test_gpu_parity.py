@@ -349,6 +349,62 @@ def test_batch_4096_properties_cfg2(oracle):
         assert np.array_equal(base[b], oracle.bootstrap(p, lwe[b], bsk, ksk, tv)), b
 
 
+def test_cfg4_per_gpu_share_scrambled_copies(oracle):
+    """BASELINE configs[3] shards 2^20 bootstraps over 8 GPUs: ONE GPU's share is a batch of 2^17 at
+    cfg2 parameters.  The batch is assembled on the device from 256 distinct ciphertexts in a
+    scrambled order; every one of the 131,072 outputs must equal the output of its source row in the
+    256-row run (whose rows 0, 100, 255 are checked against the oracle), whichever workgroup, wave of
+    the grid or key-switch tile it lands in."""
+    import torch
+    p = oracle.CFG4
+    m = pkg()
+    lwe, bsk, ksk, tv = oracle.synthetic_inputs(p, 256, cfg_index=4)
+    dev = torch.device("cuda", 0)
+    batch = 1 << 17
+    with m.Context(to_pkg_params(p)) as ctx:
+        ctx.load_bootstrapping_key(bsk, ksk)
+        base = ctx.bootstrap(lwe, tv)
+        order = torch.from_numpy(np.random.default_rng(17).integers(0, 256, size=batch)).to(dev)
+        lwe_d = torch.from_numpy(lwe.view(np.int32)).to(dev).index_select(0, order).contiguous()
+        tv_d = torch.from_numpy(tv.view(np.int32)).to(dev)
+        out_d = ctx.bootstrap(lwe_d, tv_d)
+        want_d = torch.from_numpy(base.view(np.int32)).to(dev).index_select(0, order)
+        assert tuple(out_d.shape) == (batch, p.n + 1)
+        assert torch.equal(out_d, want_d)
+        ctx.set_stream(None)
+    for b in (0, 100, 255):
+        assert np.array_equal(base[b], oracle.bootstrap(p, lwe[b], bsk, ksk, tv)), b
+
+
+def test_torch_entry_points_follow_the_current_stream(oracle):
+    """The torch-tensor entry points are stream-ordered like torch ops: inputs produced on a side
+    stream right before the call, output consumed on it right after, no host synchronisation and no
+    use_torch_stream() by the caller; then the same on the default stream."""
+    import torch
+    p = oracle.Params(1, 10, 6, oracle.Decomposer(7, 3))
+    lwe, bsk, ksk, tv = oracle.synthetic_inputs(p, 512, cfg_index=12)
+    m = pkg()
+    dev = torch.device("cuda", 0)
+    with m.Context(to_pkg_params(p)) as ctx:
+        ctx.load_bootstrapping_key(bsk, ksk)
+        want = ctx.bootstrap(lwe, tv)
+        src = torch.from_numpy(lwe.view(np.int32)).to(dev)
+        tv_d = torch.from_numpy(tv.view(np.int32)).to(dev)
+        torch.cuda.synchronize()
+        for stream in (torch.cuda.Stream(), torch.cuda.current_stream(), torch.cuda.Stream()):
+            with torch.cuda.stream(stream):
+                # a long producer chain on this stream: the input exists only once it has run
+                x = src.clone()
+                for _ in range(200):
+                    x = x + 1
+                x = x - 200
+                y = ctx.bootstrap(x, tv_d)
+                z = y.clone() ^ 0          # consumer on the same stream
+            stream.synchronize()
+            assert np.array_equal(z.cpu().numpy().view(np.uint32), want)
+        ctx.set_stream(None)
+
+
 def test_device_entry_points_are_graph_capturable(oracle):
     """The `_device` entry points promise no allocation and no synchronisation once the workspace is
     reserved: capture a whole bootstrap (blind rotation + key switch) into a HIP graph on a torch

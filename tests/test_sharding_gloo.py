@@ -65,6 +65,55 @@ def test_scatter_compute_gather(world, batch):
     assert q.get(timeout=5) is True
 
 
+def _worker_cfg4(rank, world, port, q):
+    """BASELINE configs[3]: 2^20 ciphertexts over 8 ranks.  Rows are 4 words wide here (the real 631
+    would move 2.6 GB through loopback gloo); what is checked is the partition: every rank gets
+    exactly 2^17 contiguous rows, row r of the result is f(row r of the input), keys reach all 8."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import importlib
+    pkg()
+    sh = importlib.import_module("tfhe_research_amd.sharding")
+    batch, width = 1 << 20, 4
+    like = torch.empty(0, dtype=torch.int32)
+    full = None
+    if rank == 0:
+        full = (torch.arange(batch * width, dtype=torch.int64) * 2654435761 % (1 << 31)).to(torch.int32).reshape(batch, width)
+    tv = torch.arange(width, dtype=torch.int32)
+    shapes = [(6, 3, 2, 16), (40, width)]
+    g = torch.Generator().manual_seed(8)
+    keys = [torch.randint(-(1 << 31), (1 << 31) - 1, s, dtype=torch.int32, generator=g) for s in shapes]
+    got = sh.replicate_keys(keys if rank == 0 else None, shapes, root=0, like=like)
+    seen = {}
+
+    def fn(shard, tvv):
+        seen["rows"] = shard.shape[0]
+        return _fake_bootstrap(shard, tvv)
+    out = sh.bootstrap_sharded(fn, full, tv, root=0, batch=batch, width=width, like=like)
+    ok = torch.tensor([int(seen.get("rows") == 1 << 17 and sh.shard_range(batch, world, rank) == (rank << 17, (rank + 1) << 17)
+                           and all(torch.equal(a, b) for a, b in zip(got, keys)))])
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        q.put(bool(ok.item()) and tuple(out.shape) == (batch, width) and bool(torch.equal(out, _fake_bootstrap(full, tv))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_cfg4_partition_two_to_the_twenty_over_eight_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_cfg4, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
 def test_shard_ranges_cover_the_batch():
     import importlib
     pkg()

@@ -28,7 +28,7 @@ STATUS_NAMES = {
 }
 (TFHE_ERR_INVALID_PARAMS, TFHE_ERR_UNSUPPORTED, TFHE_ERR_NO_KEY, TFHE_ERR_HIP, TFHE_ERR_INVALID_ARGUMENT,
  TFHE_ERR_NO_DEVICE, TFHE_ERR_EXACTNESS, TFHE_ERR_IO) = range(1, 9)
-FILE_BSK, FILE_KSK, FILE_LWE, FILE_GLWE, FILE_GGSW = 1, 2, 3, 4, 5
+FILE_BSK, FILE_KSK, FILE_LWE, FILE_GLWE, FILE_GGSW, FILE_WORDS = 1, 2, 3, 4, 5, 6
 DECOMPOSER_PBS, DECOMPOSER_KS = 0, 1
 BACKEND_AUTO, BACKEND_GOLDILOCKS, BACKEND_FP64, BACKEND_GOLDILOCKS_SPLIT, BACKEND_FP64_P49 = 0, 1, 2, 3, 4
 
@@ -254,7 +254,8 @@ def load_bootstrapping_key(prefix: str, params: TfheParams, aligned: bool = Fals
     out = []
     for ext, want in ((".bsk", FILE_BSK), (".ksk", FILE_KSK)):
         kind, p, al, arr = load_array(prefix + ext)
-        if kind != want or p != params or al != aligned:
+        # the file stores the 12 integer fields only (not the noise std-devs): compare those
+        if kind != want or bytes(p._c()) != bytes(params._c()) or al != aligned:
             raise TfheError(TFHE_ERR_INVALID_PARAMS, f"{prefix + ext} holds kind {kind} for {p} (aligned={al})")
         out.append(arr)
     return tuple(out)
@@ -263,6 +264,40 @@ def load_bootstrapping_key(prefix: str, params: TfheParams, aligned: bool = Fals
 def params_validate(params: TfheParams) -> int:
     cp = params._c()
     return lib().tfhe_params_validate(C.byref(cp))
+
+
+class SystemRng:
+    """Cryptographic randomness for key generation and encryption: every draw is os.urandom (the
+    kernel CSPRNG), the counterpart of the reference's `R: CryptoRng + RngCore` / thread_rng
+    (lwe.rs:55, glwe.rs:177, utils.rs:36-77).  Offers the three numpy-Generator methods the
+    convenience helpers use, so a seeded numpy Generator can stand in for it IN TESTS ONLY."""
+
+    @staticmethod
+    def _u64(count: int) -> np.ndarray:
+        return np.frombuffer(os.urandom(8 * count), dtype=np.uint64)
+
+    def integers(self, low: int, high: int, size=None, dtype=np.int64) -> np.ndarray:
+        """uniform integers in [low, high); high - low must be a power of two (2 and 2^32 are the
+        only spans the callers need, so no rejection step and no modulo bias)"""
+        span = int(high) - int(low)
+        if span <= 0 or span & (span - 1):
+            raise ValueError("SystemRng.integers: span must be a power of two")
+        shape = () if size is None else (size if isinstance(size, tuple) else (size,))
+        count = int(np.prod(shape, dtype=np.int64)) if shape else 1
+        vals = (self._u64(count) & np.uint64(span - 1)).astype(np.int64) + int(low)
+        return vals.astype(dtype).reshape(shape)
+
+    def normal(self, loc: float, scale: float, size=None) -> np.ndarray:
+        """Gaussian by Box-Muller over 53-bit uniforms from the CSPRNG"""
+        shape = () if size is None else (size if isinstance(size, tuple) else (size,))
+        count = int(np.prod(shape, dtype=np.int64)) if shape else 1
+        half = (count + 1) // 2
+        u = self._u64(2 * half)
+        u1 = ((u[:half] >> np.uint64(11)).astype(np.float64) + 1.0) * 2.0 ** -53   # (0, 1]
+        u2 = (u[half:] >> np.uint64(11)).astype(np.float64) * 2.0 ** -53            # [0, 1)
+        r = np.sqrt(-2.0 * np.log(u1))
+        z = np.concatenate([r * np.cos(2.0 * np.pi * u2), r * np.sin(2.0 * np.pi * u2)])[:count]
+        return (loc + scale * z).reshape(shape)
 
 
 class Context:
@@ -329,14 +364,29 @@ class Context:
 
     def set_stream(self, hip_stream: int | None):
         """hip_stream: a hipStream_t handle (0 = HIP's default stream); None = back to a private stream."""
+        self._bound_stream = None
         if hip_stream is None:
             self._check(lib().tfhe_context_use_own_stream(self._h))
         else:
             self._check(lib().tfhe_context_set_stream(self._h, C.c_void_p(hip_stream)))
 
     def use_torch_stream(self):
+        """Bind to torch's current stream now.  The torch-tensor entry points do this by themselves on
+        every call (_bind_torch); this is for callers that mix in host-pointer calls."""
         import torch
-        self.set_stream(torch.cuda.current_stream().cuda_stream)
+        self._bound_stream = torch.cuda.current_stream().cuda_stream
+        self.set_stream(self._bound_stream)
+
+    def _bind_torch(self):
+        """Every torch-tensor entry point runs on torch's CURRENT stream, so it is ordered after the
+        kernels that produced its inputs and before whatever consumes `out` on that stream, exactly
+        like a torch op.  Re-binding only happens when the current stream changed since the last
+        call (tfhe_context_set_stream then drains the stream it leaves: the workspace is shared)."""
+        import torch
+        s = torch.cuda.current_stream().cuda_stream
+        if getattr(self, "_bound_stream", None) != s:
+            self.set_stream(s)
+            self._bound_stream = s
 
     def synchronize(self):
         self._check(lib().tfhe_context_synchronize(self._h))
@@ -363,6 +413,7 @@ class Context:
         """bsk [n][R][k+1][N], ksk [k*N*l_ks][n+1]: reference layouts (numpy or torch device)."""
         p = self.params
         if _is_torch(bsk):
+            self._bind_torch()
             assert tuple(bsk.shape) == p.bsk_shape() and tuple(ksk.shape) == p.ksk_shape()
             self._check(lib().tfhe_load_bootstrapping_key_device(self._h, _dp(bsk), _dp(ksk)))
         else:
@@ -380,6 +431,7 @@ class Context:
         """bootstrap(): bootstrapping.rs:58-120 over a batch [batch][n+1]."""
         p = self.params
         if _is_torch(lwe_in):
+            self._bind_torch()
             import torch
             batch = lwe_in.shape[0]
             assert lwe_in.shape[1] == self.io_dim + 1
@@ -401,6 +453,7 @@ class Context:
         """bootstrapping.rs:67-105 -> GLWE accumulators [batch][k+1][N]."""
         p = self.params
         if _is_torch(lwe_in):
+            self._bind_torch()
             import torch
             batch = lwe_in.shape[0]
             if out is None:
@@ -427,6 +480,7 @@ class Context:
         """key_switch_lwe(): key_switching.rs:63-103 with the loaded KSK."""
         p = self.params
         if _is_torch(lwe_big):
+            self._bind_torch()
             import torch
             batch = lwe_big.shape[0]
             if out is None:
@@ -452,6 +506,7 @@ class Context:
     def prepare_ggsw_device(self, ggsw):
         """device u32 GGSW(s) -> device NTT-domain GGSW(s) (torch int64 tensor)."""
         import torch
+        self._bind_torch()
         count = 1 if ggsw.dim() == 3 else ggsw.shape[0]
         out = torch.empty((count, self.prepared_ggsw_words()), dtype=torch.int64, device=ggsw.device)
         self._check(lib().tfhe_prepare_ggsw_device(self._h, _dp(ggsw), C.c_size_t(count),
@@ -460,6 +515,7 @@ class Context:
 
     def external_product_prepared(self, ggsw_prepared, glwe, out=None):
         import torch
+        self._bind_torch()
         p = self.params
         batch = glwe.shape[0]
         count = ggsw_prepared.shape[0]
@@ -516,6 +572,7 @@ class Context:
     def lwe_linear(self, c0: int, ct0, c1: int = 0, ct1=None, out=None):
         """c0*ct0 + c1*ct1 (wrapping): LweCiphertext Add / Mul<u32>, lwe.rs:9-23."""
         if _is_torch(ct0):
+            self._bind_torch()
             import torch
             if out is None:
                 out = torch.empty_like(ct0)
@@ -542,6 +599,7 @@ class Context:
         arr = (C.c_uint32 * (1 << m))(*[int(v) for v in truth])
         ptrs = (_u32p * m)()
         if _is_torch(cts[0]):
+            self._bind_torch()
             import torch
             batch = cts[0].shape[0]
             for i, t in enumerate(cts):
@@ -563,6 +621,7 @@ class Context:
         """NOT without a bootstrap: (-a, enc(1) - b)."""
         p = self.params
         if _is_torch(ct):
+            self._bind_torch()
             import torch
             if out is None:
                 out = torch.empty_like(ct)
@@ -579,6 +638,7 @@ class Context:
         p = self.params
         arr = (C.c_uint32 * 4)(*[int(v) for v in truth])
         if _is_torch(ct0):
+            self._bind_torch()
             import torch
             batch = ct0.shape[0]
             if out is None:
@@ -597,6 +657,7 @@ class Context:
         p = self.params
         sk = _np(glwe_sk).reshape(p.k, p.N)
         if _is_torch(samples):
+            self._bind_torch()
             assert tuple(samples.shape[-2:]) == (p.k + 1, p.N)
             self._check(lib().tfhe_glwe_encrypt_zero_batch_device(
                 self._h, _hp(sk), _dp(samples), C.c_size_t(samples.numel() // ((p.k + 1) * p.N))))
@@ -621,6 +682,7 @@ class Context:
         sk = _np(glwe_sk).reshape(p.k, p.N)
         msg = _np(messages).reshape(-1)
         if _is_torch(samples):
+            self._bind_torch()
             assert samples.numel() == msg.size * p.R * (p.k + 1) * p.N
             self._check(lib().tfhe_ggsw_encrypt_batch_device(self._h, _hp(sk), _hp(msg), _dp(samples),
                                                              C.c_size_t(msg.size)))
@@ -635,6 +697,7 @@ class Context:
         sk = _np(lwe_sk).reshape(-1)
         dim = sk.size
         if _is_torch(samples):
+            self._bind_torch()
             assert samples.shape[-1] == dim + 1
             self._check(lib().tfhe_lwe_encrypt_batch_device(
                 self._h, _hp(sk), C.c_size_t(dim), _dp(plaintexts) if plaintexts is not None else None,
@@ -653,6 +716,7 @@ class Context:
         sk = _np(lwe_sk).reshape(-1)
         dim = sk.size
         if _is_torch(lwe):
+            self._bind_torch()
             import torch
             batch = lwe.numel() // (dim + 1)
             if out is None:
@@ -682,6 +746,7 @@ class Context:
         p = self.params
         lsk, gsk = _np(lwe_sk).reshape(p.n), _np(glwe_sk).reshape(p.k, p.N)
         if _is_torch(bsk_samples):
+            self._bind_torch()
             assert tuple(bsk_samples.shape) == p.bsk_shape() and tuple(ksk_samples.shape) == p.ksk_shape()
             self._check(lib().tfhe_bootstrapping_key_gen_device(self._h, _hp(lsk), _hp(gsk), _dp(bsk_samples),
                                                                 _dp(ksk_samples), C.c_int(int(load))))
@@ -700,11 +765,17 @@ class Context:
 
     def generate_keys(self, rng=None, load: bool = True):
         """LweSecretKey::random + GlweSecretKey::random + bootstrapping_key_gen (lwe.rs:53-60,
-        glwe.rs:176-182, bootstrapping.rs:23-56): secrets, masks and errors are drawn here with a
-        numpy Generator (the reference draws them with its rng), the key material is completed on
-        the GPU and, with `load`, installed.  -> (lwe_sk [n], glwe_sk [k][N], bsk, ksk)"""
+        glwe.rs:176-182, bootstrapping.rs:23-56): secrets, masks and errors are drawn here (the
+        reference draws them with its `R: CryptoRng + RngCore`), the key material is completed on
+        the GPU and, with `load`, installed.  -> (lwe_sk [n], glwe_sk [k][N], bsk, ksk)
+
+        Randomness: by default every draw comes from the operating system's CSPRNG (SystemRng over
+        os.urandom).  `rng=` is a TEST HOOK for reproducible runs: a numpy Generator (PCG64 etc.)
+        is NOT acceptable for real keys -- the uniform masks published in the BSK/KSK would be raw
+        consecutive outputs of the generator that produced the secret keys just before, and its
+        state can be recovered from them."""
         p = self.params
-        rng = rng if rng is not None else np.random.default_rng()
+        rng = rng if rng is not None else SystemRng()
         lwe_sk = rng.integers(0, 2, size=p.n).astype(np.uint32)
         glwe_sk = rng.integers(0, 2, size=(p.k, p.N)).astype(np.uint32)
         bsk = rng.integers(0, 1 << 32, size=p.bsk_shape(), dtype=np.uint64).astype(np.uint32)
@@ -716,9 +787,10 @@ class Context:
 
     def encrypt_bits(self, lwe_sk, messages, rng=None) -> np.ndarray:
         """LweCleartext::encode_message + encrypt_lwe_plaintext (lwe.rs:81-92,138-160) for a batch
-        of messages < 2^log_p under `lwe_sk` (any dimension) -> [batch][dim+1]"""
+        of messages < 2^log_p under `lwe_sk` (any dimension) -> [batch][dim+1].  Masks and errors
+        come from the OS CSPRNG unless the test hook `rng=` is given (see generate_keys)."""
         p = self.params
-        rng = rng if rng is not None else np.random.default_rng()
+        rng = rng if rng is not None else SystemRng()
         msg = np.asarray(messages, dtype=np.uint32).reshape(-1)
         if msg.size and int(msg.max()) >> p.log_p:
             raise TfheError(TFHE_ERR_INVALID_ARGUMENT, "assertion failed: m < 1 << log_p (lwe.rs:84)")

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -99,6 +100,9 @@ u32 gadget_top(const tfhe_context* ctx, u32 log_base) {
   return ctx->aligned ? 32u : log_base * (32u / log_base);
 }
 
+// one workgroup per sample: the grid's x dimension is a 32-bit count
+constexpr size_t kMaxBatch = 0x7FFFFFFFull;
+
 int decomposer_validate(const tfhe_decomposer_params& d) {
   if (d.log_q != 32) return 1;                        // the reference is hard-typed to u32
   if (d.log_base == 0 || d.log_base >= 32) return 2;  // 1 << (log_base - 1), 1 << log_base
@@ -130,11 +134,18 @@ int reserve(tfhe_context* ctx, size_t batch) {
   const size_t sizes[] = {batch * n1, batch * n1, batch * n1, batch * n1, batch * n1,
                           batch * glwe, batch * glwe, batch * glwe, batch * ctx->N};
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  // the old workspace is gone from here on: a failed allocation below must not leave ws_batch
+  // claiming buffers that are null (a later, smaller call would launch kernels on them)
+  ctx->ws_batch = 0;
   for (int i = 0; i < 9; ++i) {
-    if (*ptrs[i]) HIP_TRY(ctx, hipFree(*ptrs[i]));
-    *ptrs[i] = nullptr;
-    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(ptrs[i]), sizes[i] * sizeof(u32)));
+    if (*ptrs[i]) {
+      hipError_t e = hipFree(*ptrs[i]);
+      *ptrs[i] = nullptr;
+      if (e != hipSuccess) return hip_fail(ctx, e, "hipFree(workspace)");
+    }
   }
+  for (int i = 0; i < 9; ++i)
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(ptrs[i]), sizes[i] * sizeof(u32)));
   ctx->ws_batch = batch;
   return TFHE_OK;
 }
@@ -142,9 +153,12 @@ int reserve(tfhe_context* ctx, size_t batch) {
 int ensure_misc(tfhe_context* ctx, size_t bytes) {
   if (bytes <= ctx->misc_bytes) return TFHE_OK;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  if (ctx->d_misc) HIP_TRY(ctx, hipFree(ctx->d_misc));
-  ctx->d_misc = nullptr;
   ctx->misc_bytes = 0;
+  if (ctx->d_misc) {
+    hipError_t e = hipFree(ctx->d_misc);
+    ctx->d_misc = nullptr;
+    if (e != hipSuccess) return hip_fail(ctx, e, "hipFree(misc)");
+  }
   HIP_TRY(ctx, hipMalloc(&ctx->d_misc, bytes));
   ctx->misc_bytes = bytes;
   return TFHE_OK;
@@ -222,6 +236,7 @@ int check_batch_args(tfhe_context* ctx, const void* a, const void* b, const void
                      size_t tv_count) {
   if (!a || !b || !c) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer");
   if (batch == 0) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "empty batch");
+  if (batch > kMaxBatch) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "batch exceeds 2^31 - 1 (one workgroup per sample)");
   if (tv_count != 1 && tv_count != batch)
     return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "tv_count must be 1 or batch");
   return TFHE_OK;
@@ -698,6 +713,7 @@ int tfhe_external_product_prepared_device(tfhe_context* ctx, const void* ggsw_pr
     return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer / empty batch");
   if (ggsw_count != 1 && ggsw_count != batch)
     return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "ggsw_count must be 1 or batch");
+  if (batch > kMaxBatch) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "batch exceeds 2^31 - 1");
   if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
   HIP_TRY(ctx, launch::external_product(ctx->stream, ctx->field, ctx->pbs, ctx->d_tw, ggsw_prepared,
                                         ggsw_count == 1 ? 0 : ggsw_words(ctx) * ctx->parts, glwe_in,
@@ -1171,7 +1187,7 @@ int read_header(std::FILE* f, FileHeader* h) {
   for (int i = 0; i < 4; ++i) h->dims[i] = get_u32(b + 68 + 4 * i);
   h->words = get_u64(b + 88);
   h->checksum = get_u64(b + 96);
-  if (h->kind < TFHE_FILE_BSK || h->kind > TFHE_FILE_GGSW || h->ndims == 0 || h->ndims > 4) return TFHE_ERR_IO;
+  if (h->kind < TFHE_FILE_BSK || h->kind > TFHE_FILE_WORDS || h->ndims == 0 || h->ndims > 4) return TFHE_ERR_IO;
   u64 prod = 1;
   for (u32 i = 0; i < 4; ++i) {
     if (h->dims[i] == 0 || (i >= h->ndims && h->dims[i] != 1)) return TFHE_ERR_IO;
@@ -1179,6 +1195,9 @@ int read_header(std::FILE* f, FileHeader* h) {
     prod *= h->dims[i];
   }
   if (prod != h->words) return TFHE_ERR_IO;
+  // words * 4 + header must not wrap (a crafted header with words = 2^62 would otherwise pass the
+  // size check below as 0 and make the caller allocate from attacker-chosen dims)
+  if (h->words > ((u64)SIZE_MAX - kFileHeaderBytes) / sizeof(u32)) return TFHE_ERR_IO;
   return TFHE_OK;
 }
 
@@ -1186,7 +1205,7 @@ int read_header(std::FILE* f, FileHeader* h) {
 
 int tfhe_file_write(const char* path, uint32_t kind, const tfhe_params* params, uint32_t flags,
                     const uint32_t* dims, uint32_t ndims, const uint32_t* data) {
-  if (!path || !params || !dims || !data || ndims == 0 || ndims > 4 || kind < TFHE_FILE_BSK || kind > TFHE_FILE_GGSW)
+  if (!path || !params || !dims || !data || ndims == 0 || ndims > 4 || kind < TFHE_FILE_BSK || kind > TFHE_FILE_WORDS)
     return TFHE_ERR_INVALID_ARGUMENT;
   u64 words = 1;
   for (u32 i = 0; i < ndims; ++i) {

@@ -5,6 +5,8 @@
 // wave-local, no barrier inside), G = 4 at N = 2048 (one cross-wave transpose per transform).  The
 // team meets at a workgroup barrier once or twice per gadget level (two or one LDS exchange
 // buffers per group) to hand the digit spectra around.
+#include <atomic>
+
 #include "launch.h"
 
 namespace tfhe {
@@ -536,16 +538,20 @@ inline int grid_for(size_t work, int block) {
 }
 
 // Dynamic LDS above 64 KiB has to be enabled per kernel; done once per kernel and device (the
-// attribute call is not something to repeat on every launch of a short kernel).
+// attribute call is not something to repeat on every launch of a short kernel).  `done` is a bit
+// mask over devices owned by the calling launcher, which is a distinct function (and so a distinct
+// flag) per template instantiation; two host threads racing here both set the same attribute to
+// the same value, which is harmless.
 template <typename Kern>
-hipError_t allow_lds(Kern kern, size_t bytes) {
-  static bool done[64] = {};
+hipError_t allow_lds(Kern kern, size_t bytes, std::atomic<unsigned long long>& done) {
+  if (bytes <= 64 * 1024) return hipSuccess;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  if (done[dev] || bytes <= 64 * 1024) return hipSuccess;
+  const unsigned long long bit = 1ull << dev;
+  if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  if (e == hipSuccess) done[dev] = true;
+  if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
   return e;
 }
 
@@ -557,7 +563,8 @@ hipError_t launch_blind_rotate(hipStream_t s, const PbsParams& P, const void* tw
   auto tw = static_cast<const typename F::elem*>(tw_v);
   auto bsk = static_cast<const typename F::elem*>(bsk_v);
   auto kern = blind_rotate_kernel<F, LOGN, K>;
-  hipError_t e = allow_lds(kern, C::kLds);
+  static std::atomic<unsigned long long> lds_done{0};
+  hipError_t e = allow_lds(kern, C::kLds, lds_done);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(C::kThreads), C::kLds, s, P, tw, lwe_in, batch,
                      tv, tv_stride, bsk, glwe_out, lwe_extracted);
@@ -572,7 +579,8 @@ hipError_t launch_external_product(hipStream_t s, const PbsParams& P, const void
   auto tw = static_cast<const typename F::elem*>(tw_v);
   auto ggsw = static_cast<const typename F::elem*>(ggsw_v);
   auto kern = external_product_kernel<F, LOGN, K>;
-  hipError_t e = allow_lds(kern, C::kLds);
+  static std::atomic<unsigned long long> lds_done{0};
+  hipError_t e = allow_lds(kern, C::kLds, lds_done);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(C::kThreads), C::kLds, s, P, tw, ggsw,
                      ggsw_stride_words, glwe_in, ct1_inout, cmux_ct0, batch, glwe_out);
@@ -589,7 +597,8 @@ hipError_t launch_bsk_prepare(hipStream_t s, const void* tw_v, const u32* polys,
   auto tw = static_cast<const typename F::elem*>(tw_v);
   auto spectra = static_cast<typename F::elem*>(spectra_v);
   auto kern = bsk_prepare_kernel<F, LOGN>;
-  hipError_t e = allow_lds(kern, lds);
+  static std::atomic<unsigned long long> lds_done{0};
+  hipError_t e = allow_lds(kern, lds, lds_done);
   if (e != hipSuccess) return e;
   const unsigned grid = (unsigned)((poly_count + groups - 1) / groups);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, tw, polys, poly_count, spectra,
@@ -606,7 +615,8 @@ hipError_t launch_glwe_body(hipStream_t s, const void* tw_v, u32 k, const u32* r
   const size_t lds = (size_t)ntt_twiddle_words(N) * 8 + (size_t)N * 8 * groups;
   auto tw = static_cast<const typename F::elem*>(tw_v);
   auto kern = glwe_body_kernel<F, LOGN>;
-  hipError_t e = allow_lds(kern, lds);
+  static std::atomic<unsigned long long> lds_done{0};
+  hipError_t e = allow_lds(kern, lds, lds_done);
   if (e != hipSuccess) return e;
   const unsigned grid = (unsigned)((row_count + groups - 1) / groups);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, tw, k, rows, row_count, sk, dst, dst_stride,

@@ -229,9 +229,14 @@ class GraphedCircuit:
                 _run(ctx, self.steps, self.wires)
 
     def __call__(self, inputs):
+        """Stream-ordered like a torch op: the graph's stream first waits for the caller's current
+        stream (the kernels that produced `inputs`), and the caller's stream then waits for the
+        replay, so `wires` can be consumed on it without a host synchronisation."""
         import torch
+        caller = torch.cuda.current_stream(self.inputs.device)
+        self.stream.wait_stream(caller)
         with torch.cuda.stream(self.stream):
             self.inputs.copy_(inputs, non_blocking=True)
             self.graph.replay()
-        self.stream.synchronize()
+        caller.wait_stream(self.stream)
         return self.wires
