@@ -75,6 +75,16 @@ impl GpuBootstrappingKey {
         check(ctx, unsafe { tfhe_load_bootstrapping_key(ctx, flat.as_ptr(), ksk.as_slice().unwrap().as_ptr()) }, "load key");
         GpuBootstrappingKey { ctx, params }
     }
+
+    /// The same from already flattened buffers: `bsk` [n][(k+1)l][k+1][N], `ksk` [kN*l_ks][n+1]
+    /// (the layout of the on-disk format and of tests/golden/).
+    pub fn upload_flat(params: &CTfheParams, bsk: &[u32], ksk: &[u32]) -> Self {
+        let mut ctx = std::ptr::null_mut();
+        let st = unsafe { tfhe_context_create(params, 0, &mut ctx) };
+        assert!(st == 0, "tfhe_context_create: status {st}");
+        check(ctx, unsafe { tfhe_load_bootstrapping_key(ctx, bsk.as_ptr(), ksk.as_ptr()) }, "load key");
+        GpuBootstrappingKey { ctx, params: *params }
+    }
 }
 
 impl Drop for GpuBootstrappingKey {

@@ -6,7 +6,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from test_emu_kernels import FIELDS, emu, p32, p64, prepared  # noqa: F401
+from test_emu_kernels import FIELDS, p32, p64, prepared  # noqa: F401
 
 
 def signed(d):
