@@ -25,7 +25,7 @@ template <class Elem>
 struct HostTeam {
   int n, g;  // ring degree, waves per polynomial group
   int exb, groups;
-  std::vector<Elem> scratch, tw;
+  std::vector<Elem> scratch, tw, tw_natural;
   std::vector<u32> acc;
   pthread_barrier_t team_bar;
   std::vector<pthread_barrier_t> group_bars;
@@ -52,6 +52,7 @@ struct HostWave {
   const Elem* scratch_of(int s) const { return t_->scratch.data() + ((size_t)buf_ * t_->groups + s) * t_->n; }
   u32* acc() const { return t_->acc.data() + (size_t)group() * t_->n; }
   const Elem* twiddles() const { return t_->tw.data(); }
+  const Elem* twiddles_uniform() const { return t_->tw_natural.data(); }
   u32 uniform(u32 v) const { return v; }
   void compiler_fence() const {}
 };
@@ -67,8 +68,21 @@ void run_team(int logn, int groups, int g, const std::function<void(const HostWa
   team.groups = groups;
   team.scratch.resize((size_t)groups * team.n * team.exb);
   team.acc.resize((size_t)groups * team.n);
-  team.tw.resize(ntt_twiddle_words(team.n));
-  F::fill_twiddles(logn, team.tw.data());
+  // natural-order table -> the working copy's layout, as the kernels stage it into LDS
+  std::vector<elem>& natural = team.tw_natural;
+  natural.resize(ntt_twiddle_words(team.n));
+  F::fill_twiddles(logn, natural.data());
+  team.tw.resize(natural.size());
+  for (int tid = 0; tid < 64; ++tid) {
+    switch (logn * 8 + g) {
+      case 9 * 8 + 1: ntt_stage_twiddles<9, 1>(team.tw.data(), natural.data(), tid, 64); break;
+      case 10 * 8 + 1: ntt_stage_twiddles<10, 1>(team.tw.data(), natural.data(), tid, 64); break;
+      case 11 * 8 + 1: ntt_stage_twiddles<11, 1>(team.tw.data(), natural.data(), tid, 64); break;
+      case 11 * 8 + 2: ntt_stage_twiddles<11, 2>(team.tw.data(), natural.data(), tid, 64); break;
+      case 11 * 8 + 4: ntt_stage_twiddles<11, 4>(team.tw.data(), natural.data(), tid, 64); break;
+      default: std::abort();
+    }
+  }
   const int waves = groups * g;
   pthread_barrier_init(&team.team_bar, nullptr, waves * kWave);
   team.group_bars.resize(groups);

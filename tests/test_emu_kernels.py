@@ -84,10 +84,11 @@ def test_field_arithmetic(emu):
 def test_wave_ntt_matches_model(emu, logn):
     n = 1 << logn
     fwd, inv = ntt_model.tables(logn)
-    tw = np.zeros(n + 2, dtype=np.uint64)  # + psi_rev[1]*psi_rev[2], psi_rev[1]*psi_rev[3]
+    # + psi_rev[1]*psi_rev[2], psi_rev[1]*psi_rev[3] and 16 fused-stage constants (the 42-bit field's)
+    tw = np.zeros(n + 18, dtype=np.uint64)
     emu.emu_twiddles(GL, logn, p64(tw))
     assert tw[:n].tolist() == fwd
-    assert tw[n:].tolist() == [fwd[1] * fwd[2] % P, fwd[1] * fwd[3] % P]
+    assert tw[n:n + 2].tolist() == [fwd[1] * fwd[2] % P, fwd[1] * fwd[3] % P]
     rng = np.random.default_rng(logn)
     a = np.array([int(x) % P for x in rng.integers(0, 1 << 64, size=n, dtype=np.uint64)], dtype=np.uint64)
     out = np.zeros_like(a)
@@ -158,6 +159,26 @@ def test_fp_wave_ntt_roundtrip_and_convolution(emu, logn, g):
     want[: n - 1] -= full[n:]
     got = np.array([int(x) % p for x in back])
     assert np.array_equal(got, want % p)
+
+
+@pytest.mark.parametrize("logn", [9, 10, 11])
+def test_fp_fused_stage_constants(emu, logn):
+    """entries [n .. n+18) of the 42-bit field's table: w1*w2a, w1*w2b and, for the fused third stage,
+    w3[q] * (1, +-w2, +-w1, +-w1*w2) with the signs of radix-4 output q (field_fp.h::radix8_small_v)"""
+    n = 1 << logn
+    p = int(emu.emu_fp_p())
+    tw = np.zeros(n + 18)
+    emu.emu_twiddles(FP, logn, pd(tw))
+    t = [int(x) % p for x in tw]
+    w1, w2a, w2b = t[1], t[2], t[3]
+    assert t[n] == w1 * w2a % p and t[n + 1] == w1 * w2b % p
+    signs = {0: (1, 1, 1), 1: (-1, 1, -1), 2: (1, -1, -1), 3: (-1, -1, 1)}  # (b, c, d) of output q
+    for q in range(4):
+        w3, w2 = t[4 + q], (w2a if q < 2 else w2b)
+        sb, sc, sd = signs[q]
+        want = [w3, sb * w3 * w2 % p, sc * w3 * w1 % p, sd * w3 * w1 * w2 % p]
+        assert t[n + 2 + 4 * q: n + 6 + 4 * q] == [x % p for x in want], q
+    assert all(abs(x) <= p // 2 for x in tw)
 
 
 def prepared(emu, field, params, bsk, g=1):

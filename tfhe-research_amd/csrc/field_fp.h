@@ -33,7 +33,14 @@ struct FpField {
   // hooks of fields with less lazy headroom (field_fp49.h); 11 bits of it here: never needed
   static constexpr int kInverseSweepEvery = 0;
   static constexpr bool kReduceSpectrum = false;
-  static constexpr bool kSplitAccum = false;  // field_fp49.h: (h, l) accumulator pairs
+  // (h, l) accumulator pairs (field_fp49.h) are not used here: summing unreduced products would cut the
+  // multiply-accumulate from 7 to 4 instructions per term, but the second accumulator set does not fit
+  // the register budget of any shape -- measured with the 4-instruction form (accumulate inside the
+  // binade of 1.5 * 2^100): 83 spilled registers at N = 1024 (256-register budget), 37-80 at N = 512 /
+  // N = 2048 over four waves (168-register budget for three waves per SIMD), profiles/r02_*.
+  template <int E>
+  static constexpr bool split_accum() { return false; }
+  TFHE_HD static elem accum_init() { return 0.0; }
   TFHE_HD static void mac(elem, elem, elem&, elem&) {}
   TFHE_HD static elem mac_finish(elem a, elem) { return a; }
   static constexpr int kMaxRows = 1 << 10;
@@ -74,6 +81,16 @@ struct FpField {
     c = sp + tp;
     d = sp - tp;
   }
+  // Third stage fused onto radix4_small: the multiplied leg w3[q] * v_q of the stage-3 butterfly of
+  // quarter q, where v_q is output q of the radix-4 step on the small inputs (a, b, c, d), taken
+  // straight from those inputs with the four pre-multiplied coefficients k = w3[q] * (1, +-w2, +-w1,
+  // +-w1 w2) (signs folded in, mod p, balanced; fill_twiddles stores them at [N+2+4q ..]).  Every
+  // product is below 2^41 * 2^9 = 2^50, the sum of four below 2^52, and the butterfly's other leg
+  // (a radix4_small output) below 2^51.6: outputs stay below 2^52.8 < 2^53 -- exact integers, no
+  // reduction.  4 instructions.
+  TFHE_HD static elem radix8_small_v(elem a, elem b, elem c, elem d, const elem* k) {
+    return __builtin_fma(k[3], d, __builtin_fma(k[2], c, __builtin_fma(k[1], b, k[0] * a)));
+  }
   // x -> balanced residue, |x| < 2^53
   TFHE_HD static elem reduce(elem x) { return __builtin_fma(-__builtin_rint(x * PINV), P, x); }
   TFHE_HD static elem from_digit(u32 d) { return (double)(i32)d; }
@@ -111,7 +128,7 @@ struct FpField {
     return r;
   }
   static inline double balanced(u64 v) { return v > P_INT / 2 ? -(double)(P_INT - v) : (double)v; }
-  // out: n + 2 elements (wave_ntt.h::ntt_twiddle_words)
+  // out: n + 18 elements (wave_ntt.h::ntt_twiddle_words)
   static inline void fill_twiddles(int logn, elem* out) {
     const int n = 1 << logn;
     const u64 psi = powmod_u64(3, (P_INT - 1) >> (logn + 1));  // 3 generates F_p^*
@@ -126,6 +143,19 @@ struct FpField {
     }
     out[n] = balanced(mulmod_u64(raw[1], raw[2]));
     out[n + 1] = balanced(mulmod_u64(raw[1], raw[3]));
+    // radix8_small_v: quarter q of stage 3 has twiddle psi_rev[4+q]; its v leg is radix-4 output q,
+    //   q=0: a + w2a b + w1 c + w12a d      q=1: a - w2a b + w1 c - w12a d
+    //   q=2: a + w2b b - w1 c - w12b d      q=3: a - w2b b - w1 c + w12b d
+    for (int q = 0; q < 4; ++q) {
+      const u64 w3 = raw[4 + q], w2 = raw[q < 2 ? 2 : 3];
+      const u64 w12 = mulmod_u64(raw[1], w2);
+      const bool neg_b = q & 1, neg_c = q >= 2, neg_d = (q == 1 || q == 2);
+      const u64 kb = mulmod_u64(w3, w2), kc = mulmod_u64(w3, raw[1]), kd = mulmod_u64(w3, w12);
+      out[n + 2 + 4 * q + 0] = balanced(w3);
+      out[n + 2 + 4 * q + 1] = balanced(neg_b ? (P_INT - kb) % P_INT : kb);
+      out[n + 2 + 4 * q + 2] = balanced(neg_c ? (P_INT - kc) % P_INT : kc);
+      out[n + 2 + 4 * q + 3] = balanced(neg_d ? (P_INT - kd) % P_INT : kd);
+    }
   }
   static inline elem n_inv(int logn) { return balanced(powmod_u64((u64)1 << logn, P_INT - 2)); }
   static inline double exact_bits() { return 40.9; }  // |t| < p/2 = 2^41 with margin

@@ -51,8 +51,10 @@ struct Fp49Field {
   // q = rint(sum_h / p) is an integer below 2^51.7 within 1 of the true quotient and sum_h - q p is
   // an integer below 1.5 p, so the FMA returns it exactly; adding sum_l (< 4.3 p) and reducing once
   // more gives |.| <= p/2.
-  static constexpr bool kSplitAccum = true;
+  template <int E>
+  static constexpr bool split_accum() { return true; }
   static constexpr double kMacMagic = 1.5 * 1267650600228229401496703205376.0;  // 1.5 * 2^100
+  TFHE_HD static elem accum_init() { return 0.0; }
   TFHE_HD static void mac(elem d, elem k, elem& acc_h, elem& acc_l) {
     const double t = __builtin_fma(d, k, kMacMagic);
     const double h = t - kMacMagic;
@@ -77,6 +79,7 @@ struct Fp49Field {
   TFHE_HD static elem mul_small(elem a, elem w) { return mul(a, w); }
   static constexpr bool kFuseFirstTwo = false;
   TFHE_HD static void radix4_small(elem&, elem&, elem&, elem&, elem, elem, elem, elem, elem) {}
+  TFHE_HD static elem radix8_small_v(elem, elem, elem, elem, const elem*) { return 0.0; }
   // x -> balanced residue, |x| < 2^53
   TFHE_HD static elem reduce(elem x) { return __builtin_fma(-__builtin_rint(x * PINV), P, x); }
   TFHE_HD static elem from_digit(u32 d) { return (double)(i32)d; }
@@ -106,7 +109,7 @@ struct Fp49Field {
     return r;
   }
   static inline double balanced(u64 v) { return v > P_INT / 2 ? -(double)(P_INT - v) : (double)v; }
-  // out: n + 2 elements (wave_ntt.h::ntt_twiddle_words); the two extra ones are unused here
+  // out: n + 18 elements (wave_ntt.h::ntt_twiddle_words); the extra ones are unused here
   static inline void fill_twiddles(int logn, elem* out) {
     const int n = 1 << logn;
     const u64 psi = powmod_u64(3, (P_INT - 1) >> (logn + 1));  // 3 generates F_p^*
@@ -121,6 +124,7 @@ struct Fp49Field {
     }
     out[n] = balanced(mulmod_u64(raw[1], raw[2]));
     out[n + 1] = balanced(mulmod_u64(raw[1], raw[3]));
+    for (int i = 2; i < 18; ++i) out[n + i] = 0.0;  // fused-stage constants of the 42-bit field: unused here
   }
   static inline elem n_inv(int logn) { return balanced(powmod_u64((u64)1 << logn, P_INT - 2)); }
   static inline double exact_bits() { return 48.25; }  // |t| < p/2 = 2^48.254

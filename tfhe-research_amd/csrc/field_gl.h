@@ -16,7 +16,9 @@ struct GlFieldT {
   // hooks of the lazily-reduced fp64 fields; canonical arithmetic never needs them
   static constexpr int kInverseSweepEvery = 0;
   static constexpr bool kReduceSpectrum = false;
-  static constexpr bool kSplitAccum = false;  // field_fp49.h: (h, l) accumulator pairs
+  template <int E>
+  static constexpr bool split_accum() { return false; }  // field_fp49.h / field_fp.h: (h, l) accumulator pairs
+  TFHE_HD static elem accum_init() { return 0; }
   TFHE_HD static void mac(elem, elem, elem&, elem&) {}
   TFHE_HD static elem mac_finish(elem a, elem) { return a; }
   static constexpr int kMaxRows = 1 << 20;
@@ -30,6 +32,7 @@ struct GlFieldT {
   TFHE_HD static elem mul_small(elem a, elem w) { return gl::mul(a, w); }
   static constexpr bool kFuseFirstTwo = false;  // canonical u64 arithmetic gains nothing from it
   TFHE_HD static void radix4_small(elem&, elem&, elem&, elem&, elem, elem, elem, elem, elem) {}
+  TFHE_HD static elem radix8_small_v(elem, elem, elem, elem, const elem*) { return 0; }
   // gadget digit (wrapped u32 holding a small signed integer) -> field element
   TFHE_HD static elem from_digit(u32 d) { return gl::from_i32(d); }
   // key word -> field element of spectrum `part`
@@ -51,7 +54,7 @@ struct GlFieldT {
   }
 
   // ---- host-side constants ----
-  // out: n + 2 elements (wave_ntt.h::ntt_twiddle_words)
+  // out: n + 18 elements (wave_ntt.h::ntt_twiddle_words)
   static inline void fill_twiddles(int logn, elem* out) {
     const int n = 1 << logn;
     const u64 psi = gl::root_of_unity(logn + 1);
@@ -64,6 +67,7 @@ struct GlFieldT {
     }
     out[n] = gl::mul(out[1], out[2]);
     out[n + 1] = gl::mul(out[1], out[3]);
+    for (int i = 2; i < 18; ++i) out[n + i] = 0;  // fused-stage constants of the 42-bit fp64 field: unused here
   }
   static inline elem n_inv(int logn) { return gl::inv((u64)1 << logn); }
   // log2 of the largest |integer convolution value| this field lifts exactly

@@ -32,6 +32,7 @@ struct DeviceWave {
   Elem* scratch_;             // my group's exchange / transpose buffer in use
   u32* acc_;
   const Elem* tw_;
+  const Elem* twg_;           // the natural-order table in global memory (kernel argument: uniform)
   int group_;                 // polynomial / output column of my group
   unsigned group_stride_;     // bytes of LDS per group
   unsigned buffer_bytes_;     // bytes of one exchange buffer (EXB of them per group, back to back)
@@ -76,6 +77,7 @@ struct DeviceWave {
   }
   __device__ __forceinline__ u32* acc() const { return acc_; }
   __device__ __forceinline__ const Elem* twiddles() const { return tw_; }
+  __device__ __forceinline__ const Elem* twiddles_uniform() const { return twg_; }
   __device__ __forceinline__ u32 uniform(u32 v) const { return __builtin_amdgcn_readfirstlane(v); }
   // compiler-only barrier: memory operations are not moved across it
   __device__ __forceinline__ void compiler_fence() const { asm volatile("" ::: "memory"); }
@@ -120,7 +122,7 @@ make_wave(unsigned char* smem, const typename F::elem* tw_global) {
   typedef typename F::elem elem;
   using C = TeamCfg<LOGN, K>;
   elem* tw = reinterpret_cast<elem*>(smem);
-  for (int i = threadIdx.x; i < ntt_twiddle_words(C::N); i += blockDim.x) tw[i] = tw_global[i];
+  ntt_stage_twiddles<LOGN, C::G>(tw, tw_global, (int)threadIdx.x, (int)blockDim.x);
   __syncthreads();
   DeviceWave<elem, C::G, C::EXB> w;
   w.group_ = (int)(threadIdx.x / (64u * C::G));
@@ -129,6 +131,7 @@ make_wave(unsigned char* smem, const typename F::elem* tw_global) {
   w.team_base_ = smem + C::kTwBytes;
   unsigned char* base = w.team_base_ + (size_t)w.group_ * C::kGroupLds;
   w.tw_ = tw;
+  w.twg_ = tw_global;
   w.scratch_ = reinterpret_cast<elem*>(base);
   w.acc_ = reinterpret_cast<u32*>(base + (size_t)C::N * 8 * C::EXB);
   return w;
@@ -148,7 +151,7 @@ __global__ void __launch_bounds__(256) bsk_prepare_kernel(const typename F::elem
   constexpr int N = 1 << LOGN;
   constexpr int G = GroupOf<LOGN>::value;
   elem* twl = reinterpret_cast<elem*>(g_smem);
-  for (int i = threadIdx.x; i < ntt_twiddle_words(N); i += blockDim.x) twl[i] = tw[i];
+  ntt_stage_twiddles<LOGN, G>(twl, tw, (int)threadIdx.x, (int)blockDim.x);
   __syncthreads();
   const int group = (int)(threadIdx.x / (64u * G));
   const int groups = (int)(blockDim.x / (64u * G));
@@ -165,6 +168,7 @@ __global__ void __launch_bounds__(256) bsk_prepare_kernel(const typename F::elem
   w.buffer_bytes_ = 0;
   w.team_base_ = nullptr;
   w.tw_ = twl;
+  w.twg_ = tw;
   w.scratch_ = reinterpret_cast<elem*>(g_smem + (size_t)ntt_twiddle_words(N) * 8 + (size_t)group * N * 8);
   w.acc_ = nullptr;
   bsk_prepare_wave<F, LOGN, G>(w, polys + poly * N, spectra + poly * N * F::kParts, n_inv);
@@ -200,6 +204,16 @@ blind_rotate_kernel(PbsParams P, const typename F::elem* __restrict__ tw,
 }
 
 // ------------------------------------------------------------------------------ external product
+// Persistent grid: a team takes samples blockIdx.x, blockIdx.x + gridDim.x, ... so the twiddle
+// table is staged into LDS once per team instead of once per sample (the launcher sizes the grid to
+// the teams that are resident at once).  Both forms of the reference call go through ONE
+// instantiation of the team code: the plain product (ggsw.rs:132-161) and the CMUX form
+// (ggsw.rs:164-178: ct1 -= ct0 is written back, the product is added to ct0); `cmux_ct0` is a
+// kernel argument, so the selects below are wave-uniform branches.  (Measured and dropped,
+// profiles/r02_external_product_experiments.txt: fetching the next sample's operand early -- by
+// LDS-DMA or into registers behind the inverse transforms --, starting the teams out of phase and
+// oversubscribing the grid all left the time per product unchanged within 2 %; with loads and
+// stores compiled out the kernel is only 4 % faster: it is the team code itself that bounds it.)
 template <class F, int LOGN, int K>
 __global__ void __launch_bounds__((TeamCfg<LOGN, K>::kThreads),
                                   (F::kId == FpField::kId || F::kId == Fp49Field::kId
@@ -213,26 +227,26 @@ external_product_kernel(PbsParams P, const typename F::elem* __restrict__ tw,
   constexpr int N = C::N;
   constexpr int G = C::G;
   auto w = make_wave<F, LOGN, K>(g_smem, tw);
-  const size_t sample = blockIdx.x;
-  const size_t poly = (sample * (size_t)(K + 1) + w.group()) * N;  // my polynomial / my output column
-  const typename F::elem* g = ggsw + sample * ggsw_stride_words;
-  u32* dst = glwe_out + poly;
-  if (cmux_ct0 == nullptr) {
-    const u32* in = glwe_in + poly;
-    auto src = [&](int j) -> u32 { return in[j]; };
-    auto out = [&](int j, u32 v) { dst[j] = v; };
-    external_product_team<F, LOGN, K, G>(w, P, g, src, out);
-  } else {
+  const bool is_cmux = cmux_ct0 != nullptr;
+  // every wave of the team walks the same samples: the barriers inside the team code stay matched
+  for (size_t sample = blockIdx.x; sample < batch; sample += gridDim.x) {
+    const size_t poly = (sample * (size_t)(K + 1) + w.group()) * N;  // my polynomial / my output column
+    const typename F::elem* g = ggsw + sample * ggsw_stride_words;
+    const u32* in = is_cmux ? ct1_inout + poly : glwe_in + poly;
     const u32* c0 = cmux_ct0 + poly;
     u32* c1 = ct1_inout + poly;
-    // *glwe_ciphertext1 -= glwe_ciphertext0 (ggsw.rs:171): each coefficient is read and written
-    // by the one lane that owns index j, so the in-place update is race free
+    u32* dst = glwe_out + poly;
+    // CMUX: each coefficient is read and written by the one lane that owns index j, so the in-place
+    // update of ct1 (*glwe_ciphertext1 -= glwe_ciphertext0, ggsw.rs:171) is race free
     auto src = [&](int j) -> u32 {
-      const u32 d = c1[j] - c0[j];
-      c1[j] = d;
+      u32 d = __builtin_nontemporal_load(&in[j]);
+      if (is_cmux) {
+        d -= c0[j];
+        c1[j] = d;
+      }
       return d;
     };
-    auto out = [&](int j, u32 v) { dst[j] = v + c0[j]; };
+    auto out = [&](int j, u32 v) { __builtin_nontemporal_store(is_cmux ? v + c0[j] : v, &dst[j]); };
     external_product_team<F, LOGN, K, G>(w, P, g, src, out);
   }
 }
@@ -440,7 +454,7 @@ __global__ void __launch_bounds__(256) glwe_body_kernel(const typename F::elem* 
   constexpr int N = 1 << LOGN;
   constexpr int G = GroupOf<LOGN>::value;
   elem* twl = reinterpret_cast<elem*>(g_smem);
-  for (int i = threadIdx.x; i < ntt_twiddle_words(N); i += blockDim.x) twl[i] = tw[i];
+  ntt_stage_twiddles<LOGN, G>(twl, tw, (int)threadIdx.x, (int)blockDim.x);
   __syncthreads();
   const int group = (int)(threadIdx.x / (64u * G));
   const int groups = (int)(blockDim.x / (64u * G));
@@ -459,6 +473,7 @@ __global__ void __launch_bounds__(256) glwe_body_kernel(const typename F::elem* 
   w.buffer_bytes_ = 0;
   w.team_base_ = nullptr;
   w.tw_ = twl;
+  w.twg_ = tw;
   w.scratch_ = reinterpret_cast<elem*>(g_smem + (size_t)ntt_twiddle_words(N) * 8 + (size_t)group * N * 8);
   w.acc_ = nullptr;
   const u32* masks = rows + row * (size_t)(k + 1) * N;
@@ -582,7 +597,21 @@ hipError_t launch_external_product(hipStream_t s, const PbsParams& P, const void
   static std::atomic<unsigned long long> lds_done{0};
   hipError_t e = allow_lds(kern, C::kLds, lds_done);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(C::kThreads), C::kLds, s, P, tw, ggsw,
+  // persistent grid: as many teams as the device keeps resident at once (LDS or registers decide)
+  static std::atomic<int> resident{0};
+  int teams = resident.load(std::memory_order_relaxed);
+  if (teams == 0) {
+    int dev = 0, cus = 0, per_cu = 0;
+    e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e == hipSuccess)
+      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), C::kThreads, C::kLds);
+    if (e != hipSuccess) return e;
+    teams = cus * (per_cu > 0 ? per_cu : 1);
+    resident.store(teams, std::memory_order_relaxed);
+  }
+  const size_t grid = batch < (size_t)teams ? batch : (size_t)teams;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C::kThreads), C::kLds, s, P, tw, ggsw,
                      ggsw_stride_words, glwe_in, ct1_inout, cmux_ct0, batch, glwe_out);
   return hipGetLastError();
 }
@@ -678,6 +707,16 @@ int field_parts(int field) { return (field == kFieldGoldilocks || field == kFiel
   }
 #endif
 
+#if defined(TFHE_DEV_FIELD_FP_ONLY)  // dev builds: only the fp64-p42 field (fast iteration on the kernels)
+#define TFHE_DISPATCH_FIELD(field, BODY)                                      \
+  do {                                                                        \
+    if ((field) == kFieldFp64) {                                              \
+      typedef FpField FF;                                                     \
+      BODY                                                                    \
+    }                                                                         \
+    return hipErrorInvalidValue;                                              \
+  } while (0)
+#else
 #define TFHE_DISPATCH_FIELD(field, BODY)                                      \
   do {                                                                        \
     if ((field) == kFieldGoldilocks) {                                        \
@@ -695,6 +734,7 @@ int field_parts(int field) { return (field == kFieldGoldilocks || field == kFiel
     }                                                                         \
     return hipErrorInvalidValue;                                              \
   } while (0)
+#endif
 
 hipError_t bsk_prepare(hipStream_t s, int field, u32 log_n, const void* tw, const u32* polys,
                        size_t poly_count, void* spectra) {

@@ -70,6 +70,31 @@ TFHE_HD u32 decompose_limb(u32 v, u32 shift, u32 log_base, u32& carry) {
   return res - (carry_mask << 1);
 }
 
+// The same limb for the hot loop, 7 instructions instead of 11, no state besides `v` itself: the
+// carry travels between limbs as bit log_base-1 of v -- a bit of the limb just consumed (or, before the
+// first limb, a bit that `carry_width` = 0 hides), dead from then on.  The limb is one bit-field
+// extract, the carry-in another (width `carry_width`: 0 for the lowest limb, 1 after), the carry-out
+// is written back by one bit-field insert of res's bit log_base-1, digit = res - 2 * (res & B/2) is
+// one multiply-add.
+TFHE_HD u32 decompose_limb_fast(u32& v, u32 shift, u32 log_base, u32 carry_width) {
+  const u32 half = 1u << (log_base - 1);
+#if defined(__HIP_DEVICE_COMPILE__)
+  const u32 res = __builtin_amdgcn_ubfe(v, shift, log_base) + __builtin_amdgcn_ubfe(v, log_base - 1, carry_width);
+  const u32 hb = res & half;
+  u32 digit;
+  // (res, hb < 2^17: the signed 24-bit multiply-add is exact) digit = hb * -2 + res
+  asm("v_mad_i32_i24 %0, %1, -2, %2" : "=v"(digit) : "v"(hb), "v"(res));
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(v) : "s"(half), "v"(res), "v"(v));  // v = (res & half) | (v & ~half)
+  return digit;
+#else
+  const u32 cin = carry_width ? ((v >> (log_base - 1)) & 1u) : 0u;
+  const u32 res = ((v >> shift) & ((1u << log_base) - 1u)) + cin;
+  const u32 hb = res & half;
+  v = hb | (v & ~half);
+  return res - (hb << 1);
+#endif
+}
+
 // utils.rs:13-33 with log_from = 32: round(v * 2N / 2^32) mod 2N
 TFHE_HD u32 switch_modulus_2n(u32 v, u32 log_n) {
   const u32 sh = 32u - (log_n + 1u);
@@ -117,21 +142,23 @@ TFHE_HD void external_product_team(const Ctx& c, const PbsParams& P, const typen
   constexpr int PARTS = F::kParts;
   const int lane = c.tid();   // thread index inside my polynomial's group of G waves
   const int me = c.group();   // polynomial / output column owned by my group
+  constexpr bool SPLIT = F::template split_accum<E>();
 
   elem accum[PARTS][E];
-  // second accumulator set of fields that add up unreduced (h, l) product pairs (F::kSplitAccum)
-  elem accum_lo[F::kSplitAccum ? PARTS : 1][F::kSplitAccum ? E : 1];
+  // second accumulator set of fields that add up unreduced (h, l) product pairs (F::split_accum)
+  elem accum_lo[SPLIT ? PARTS : 1][SPLIT ? E : 1];
 #pragma unroll
   for (int q = 0; q < PARTS; ++q)
 #pragma unroll
     for (int r = 0; r < E; ++r) {
-      accum[q][r] = F::zero();
-      if (F::kSplitAccum) accum_lo[F::kSplitAccum ? q : 0][F::kSplitAccum ? r : 0] = F::zero();
+      accum[q][r] = SPLIT ? F::accum_init() : F::zero();
+      if (SPLIT) accum_lo[SPLIT ? q : 0][SPLIT ? r : 0] = F::zero();
     }
 
-  // v[r]: rounded coefficient.  The running carry of the digit chain lives in bit 0 of v[r]: the
-  // lowest kept limb is extracted first (its carry-in is 0 by construction), after that bit 0 is
-  // never part of a limb again (every later limb starts at bit >= log_base >= 1).
+  // v[r]: rounded coefficient; hb[r]: carry state of its digit chain (decompose_limb_fast), 0 before
+  // the lowest kept limb (whose carry-in is 0 by construction)
+  // v[r]: rounded coefficient; once a limb has been consumed its bit log_base-1 carries the digit
+  // chain's carry to the next limb (decompose_limb_fast)
   u32 v[E];
 #pragma unroll
   for (int r = 0; r < E; ++r) v[r] = round_value(src(r * T + lane), P.ignored_bits);
@@ -173,14 +200,9 @@ TFHE_HD void external_product_team(const Ctx& c, const PbsParams& P, const typen
     c.compiler_fence();
     {
       elem work[E];
-      const u32 carry_mask = (t == 0) ? 0u : 1u;  // wave-uniform
+      const u32 carry_width = (t == 0) ? 0u : 1u;  // wave-uniform: the lowest kept limb has no carry-in
 #pragma unroll
-      for (int r = 0; r < E; ++r) {
-        u32 carry = v[r] & carry_mask;
-        const u32 digit = decompose_limb(v[r], shift, P.log_base, carry);
-        v[r] = (v[r] & ~1u) | carry;
-        work[r] = F::from_digit(digit);
-      }
+      for (int r = 0; r < E; ++r) work[r] = F::from_digit(decompose_limb_fast(v[r], shift, P.log_base, carry_width));
       // digits are tiny (|d| <= B <= 2^F::kSmallBits, enforced when the context picks the field):
       // the first butterfly stage uses F::mul_small.  A team barrier precedes every level (the
       // caller's for level 0, the previous level's below) and nobody reads this buffer after it.
@@ -218,8 +240,8 @@ TFHE_HD void external_product_team(const Ctx& c, const PbsParams& P, const typen
       c.compiler_fence();  // keep the next chunk's loads above this chunk's arithmetic
 #pragma unroll
       for (int r = 0; r < CH; ++r) {
-        if (F::kSplitAccum)
-          F::mac(d[r], kbuf[cur][r], accum[q][r0 + r], accum_lo[F::kSplitAccum ? q : 0][F::kSplitAccum ? r0 + r : 0]);
+        if (SPLIT)
+          F::mac(d[r], kbuf[cur][r], accum[q][r0 + r], accum_lo[SPLIT ? q : 0][SPLIT ? r0 + r : 0]);
         else
           accum[q][r0 + r] = F::add(accum[q][r0 + r], F::mul(d[r], kbuf[cur][r]));
       }
@@ -232,7 +254,7 @@ TFHE_HD void external_product_team(const Ctx& c, const PbsParams& P, const typen
     constexpr int q = decltype(part_c)::value;
 #pragma unroll
     for (int r = 0; r < E; ++r)
-      accum[q][r] = F::kSplitAccum ? F::mac_finish(accum[q][r], accum_lo[F::kSplitAccum ? q : 0][F::kSplitAccum ? r : 0])
+      accum[q][r] = SPLIT ? F::mac_finish(accum[q][r], accum_lo[SPLIT ? q : 0][SPLIT ? r : 0])
                                    : F::before_inverse(accum[q][r]);
     ntt_inverse<F, LOGN, G>(ci, accum[q]);
   });

@@ -32,7 +32,8 @@
 //
 // Ctx (GPU: DeviceWave in kernels.hip; CPU tests: the SIMT emulator in tests/emu) provides
 //   int tid() const;  void poly_sync() const;  void wave_sync() const;  elem* scratch() const;
-//   const elem* twiddles() const;
+//   const elem* twiddles() const;          working copy of the table (ntt_twiddle_slot order; LDS)
+//   const elem* twiddles_uniform() const;  the natural-order table behind a wave-uniform pointer
 // and, for the team code in pbs_wave.h, int exchange_buffers() const (1 or 2 LDS buffers per group)
 // and Ctx with_exchange_buffer(int i) const (a copy whose scratch()/scratch_of() use buffer i).
 #pragma once
@@ -42,8 +43,9 @@
 
 namespace tfhe {
 
-// elements of the twiddle table of a ring of degree n (see above)
-constexpr int ntt_twiddle_words(int n) { return n + 2; }
+// elements of the twiddle table of a ring of degree n: psi_rev[n], the two products of the fused
+// first two stages and the 16 coefficients of the fused third one (F::radix8_small_v)
+constexpr int ntt_twiddle_words(int n) { return n + 18; }
 
 template <int LOGN, int G = 1>
 struct NttShape {
@@ -66,6 +68,48 @@ struct NttShape {
   static constexpr int kLo3 = (kPasses == 3) ? 0 : kTBits - 2 * kEBits;
   static constexpr int kLo4 = 0;
 };
+
+// Where the working copy of the twiddle table (LDS on the GPU) keeps psi_rev[idx].  Stage b of a
+// transform reads psi_rev[m + hi * cnt + i] with m = N >> (b+1), hi = tid >> LO (LO = low bit of the
+// stage's register window), i < cnt = 2^(LO+e-b-1) the twiddle of register pair group i.  In table
+// order the lanes of one read are cnt * 8 bytes apart -- a power of two, up to 8-way bank conflicts in
+// the low windows (PMC round 1: a third of the LDS-active cycles were conflict cycles).  The working
+// copy therefore stores the [H][cnt] block of every stage transposed, at m + i * H + hi with
+// H = 2^(TB-LO): one read touches H consecutive 8-byte words (lanes with equal hi share a word), which
+// is conflict free, and the address is one per-pass lane term plus an immediate.  The host-side table
+// (F::fill_twiddles) stays in natural order; the permutation is applied while staging it
+// (ntt_stage_twiddles).  Entries 0 and >= N (the fused-stage constants) stay where they are.
+template <int LOGN, int G>
+TFHE_HD int ntt_stage_window_lo(int b) {
+  using S = NttShape<LOGN, G>;
+  return b >= S::kLo1 ? S::kLo1 : b >= S::kLo2 ? S::kLo2 : b >= S::kLo3 ? S::kLo3 : S::kLo4;
+}
+
+#ifndef TFHE_TW_TRANSPOSED
+#define TFHE_TW_TRANSPOSED 0
+#endif
+#ifndef TFHE_RADIX8
+#define TFHE_RADIX8 1
+#endif
+template <int LOGN, int G>
+TFHE_HD int ntt_twiddle_slot(int idx) {
+  using S = NttShape<LOGN, G>;
+  if (!TFHE_TW_TRANSPOSED || idx <= 0 || idx >= S::kN) return idx;
+  const int fl = 31 - __builtin_clz((unsigned)idx);  // m = 2^fl
+  const int b = LOGN - 1 - fl;
+  const int lo = ntt_stage_window_lo<LOGN, G>(b);
+  const int cnt_bits = lo + S::kEBits - b - 1;  // log2 of twiddles per lane at this stage
+  const int h_bits = S::kTBits - lo;            // log2 of distinct lane terms
+  const int local = idx - (1 << fl);
+  const int hi = local >> cnt_bits, i = local & ((1 << cnt_bits) - 1);
+  return (1 << fl) + (i << h_bits) + hi;
+}
+
+// copy the natural-order table `src` (ntt_twiddle_words(N) elements) into the working copy `dst`
+template <int LOGN, int G, class Elem>
+TFHE_HD void ntt_stage_twiddles(Elem* dst, const Elem* src, int tid, int nthreads) {
+  for (int i = tid; i < ntt_twiddle_words(1 << LOGN); i += nthreads) dst[ntt_twiddle_slot<LOGN, G>(i)] = src[i];
+}
 
 // XOR swizzle of the transpose buffer (element = 8 bytes).  Each one makes every ds_write_b64 and
 // ds_read_b64 of both transposes, in both directions, bank-conflict free (tools/ntt_model.py).
@@ -148,31 +192,59 @@ TFHE_HD void ntt_pass_forward(const Ctx& c, typename F::elem (&x)[NttShape<LOGN,
   typedef typename F::elem elem;
   constexpr int E = NttShape<LOGN, G>::kE;
   constexpr int e = NttShape<LOGN, G>::kEBits;
+  constexpr int N = NttShape<LOGN, G>::kN;
+  constexpr int H = 1 << (NttShape<LOGN, G>::kTBits - LO);  // distinct lane terms (ntt_twiddle_slot)
   const elem* tw = c.twiddles();
+  // Top window (LO = TB): hi = 0, every lane uses the same twiddles.  They are read from the
+  // natural-order table through a wave-uniform pointer (global memory on the GPU: scalar loads into
+  // SGPRs -- no LDS reads, no vector registers; the fp64 instructions take them as their one scalar
+  // operand), the lower windows from the working copy (LDS).
+  constexpr bool TOP = LO == NttShape<LOGN, G>::kTBits;
+  const elem* twu = c.twiddles_uniform();
   const int hi = c.tid() >> LO;
-  // The two top stages of the whole transform on small inputs (gadget digits): in a field with
-  // kFuseFirstTwo they collapse into one exact radix-4 step without any modular reduction
-  // (F::radix4_small).  Twiddles: psi_rev[1], psi_rev[2], psi_rev[3] and their two products
-  // psi_rev[1]*psi_rev[2], psi_rev[1]*psi_rev[3], which fill_twiddles stores at [N] and [N+1].
+  // The top stages of the whole transform on small inputs (gadget digits): in a field with
+  // kFuseFirstTwo the first two collapse into one exact radix-4 step without any modular reduction
+  // (F::radix4_small; twiddles psi_rev[1..3] and their products at [N], [N+1]), and the third one
+  // takes its multiplied leg w3 * v straight from the four small inputs of v's radix-4 group with the
+  // 16 pre-multiplied coefficients at [N+2 .. N+17] (F::radix8_small_v): 34 instructions per eight
+  // elements instead of 52.  (The top window's twiddles are the same for every lane: hi = 0.)
   constexpr bool FUSE = SMALL_FIRST && F::kFuseFirstTwo && BHI == LOGN - 1 && BHI - BLO >= 1;
+  constexpr bool FUSE3 = TFHE_RADIX8 && FUSE && BHI - BLO >= 2;
   if constexpr (FUSE) {
-    constexpr int N = NttShape<LOGN, G>::kN;
-    constexpr int s1 = 1 << (BHI - LO), s2 = s1 >> 1;
-    const elem w1 = tw[1], w2a = tw[2], w2b = tw[3], w12a = tw[N], w12b = tw[N + 1];
+    constexpr int s1 = 1 << (BHI - LO), s2 = s1 >> 1, s3 = s2 >> 1;
+    static_assert(!FUSE || TOP, "the fused stages are the top ones");
+    const elem w1 = twu[1], w2a = twu[2], w2b = twu[3], w12a = twu[N], w12b = twu[N + 1];
+    if constexpr (FUSE3) {
 #pragma unroll
-    for (int r = 0; r < s2; ++r)
-      F::radix4_small(x[r], x[r + s2], x[r + s1], x[r + s1 + s2], w1, w2a, w2b, w12a, w12b);
+      for (int r = 0; r < s3; ++r) {
+        const elem va = x[r + s3], vb = x[r + s3 + s2], vc = x[r + s3 + s1], vd = x[r + s3 + s1 + s2];
+        F::radix4_small(x[r], x[r + s2], x[r + s1], x[r + s1 + s2], w1, w2a, w2b, w12a, w12b);
+        constexpr int pos[4] = {0, s2, s1, s1 + s2};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const elem z = F::radix8_small_v(va, vb, vc, vd, twu + N + 2 + 4 * q);
+          const elem u = x[r + pos[q]];
+          x[r + pos[q]] = F::add(u, z);
+          x[r + pos[q] + s3] = F::sub(u, z);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < s2; ++r)
+        F::radix4_small(x[r], x[r + s2], x[r + s1], x[r + s1 + s2], w1, w2a, w2b, w12a, w12b);
+    }
   }
 #pragma unroll
-  for (int b = FUSE ? BHI - 2 : BHI; b >= BLO; --b) {
+  for (int b = FUSE3 ? BHI - 3 : FUSE ? BHI - 2 : BHI; b >= BLO; --b) {
     const int rb = b - LO;
-    const int m = NttShape<LOGN, G>::kN >> (b + 1);
-    const int base = m + (hi << (LO + e - b - 1));
+    const int m = N >> (b + 1);
 #pragma unroll
     for (int r0 = 0; r0 < E; ++r0) {
       if ((r0 >> rb) & 1) continue;
       const int r1 = r0 | (1 << rb);
-      const elem w = tw[base + (r0 >> (rb + 1))];
+      const elem w = TOP ? twu[m + (r0 >> (rb + 1))]
+                     : TFHE_TW_TRANSPOSED ? tw[m + (r0 >> (rb + 1)) * H + hi]
+                                          : tw[m + (hi << (LO + e - b - 1)) + (r0 >> (rb + 1))];
       const elem u = x[r0];
       const elem v = (SMALL_FIRST && b == BHI) ? F::mul_small(x[r1], w) : F::mul(x[r1], w);
       x[r0] = F::add(u, v);
@@ -187,19 +259,25 @@ TFHE_HD void ntt_pass_inverse(const Ctx& c, typename F::elem (&x)[NttShape<LOGN,
   typedef typename F::elem elem;
   constexpr int E = NttShape<LOGN, G>::kE;
   constexpr int e = NttShape<LOGN, G>::kEBits;
+  constexpr int H = 1 << (NttShape<LOGN, G>::kTBits - LO);
+  constexpr bool TOP = LO == NttShape<LOGN, G>::kTBits;  // lane-uniform twiddles: see ntt_pass_forward
   const elem* tw = c.twiddles();
+  const elem* twu = c.twiddles_uniform();
   const int hi = c.tid() >> LO;
 #pragma unroll
   for (int b = BLO; b <= BHI; ++b) {
     const int rb = b - LO;
     const int h = NttShape<LOGN, G>::kN >> (b + 1);
-    // psi^-bitrev(h+i) = -psi_rev[2h-1-i]
-    const int top = 2 * h - 1 - (hi << (LO + e - b - 1));
+    // psi^-bitrev(h+j) = -psi_rev[2h-1-j]: table index h + (H-1-hi) * cnt + (cnt-1-i) for register
+    // pair group i, which the working copy keeps at h + (cnt-1-i) * H + (H-1-hi) (ntt_twiddle_slot)
+    const int cnt = 1 << (LO + e - b - 1);
 #pragma unroll
     for (int r0 = 0; r0 < E; ++r0) {
       if ((r0 >> rb) & 1) continue;
       const int r1 = r0 | (1 << rb);
-      const elem w = tw[top - (r0 >> (rb + 1))];
+      const elem w = TOP ? twu[2 * h - 1 - (r0 >> (rb + 1))]
+                     : TFHE_TW_TRANSPOSED ? tw[h + (cnt - 1 - (r0 >> (rb + 1))) * H + (H - 1 - hi)]
+                                          : tw[2 * h - 1 - (hi << (LO + e - b - 1)) - (r0 >> (rb + 1))];
       const elem u = x[r0];
       const elem v = x[r1];
       x[r0] = F::add(u, v);

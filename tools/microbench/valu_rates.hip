@@ -63,6 +63,35 @@ DEF_KERNEL32(k_mad24, I_MAD24)
 DEF_KERNEL32(k_mulhi24, I_MULHI24)
 DEF_KERNEL32(k_fma32, I_FMA32)
 DEF_KERNEL32(k_cndmask, I_CNDMASK)
+// v_cndmask_b32 again with its lane mask defined inside the block: k_cndmask above reads a VCC that
+// nothing in the kernel ever wrote, and round 1 measured 22.8 cycles for it at every occupancy -- five
+// times the other VALU rows.  k_cndmask_vccset writes VCC once per 16 selects (SALU), k_cndmask_sgpr
+// takes the mask from an ordinary SGPR pair (VOP3 form, what the compiler emits for a select on a
+// wave-uniform condition), k_cndmask_vcmp produces VCC with a VALU compare before every select (what
+// a per-lane conditional correction such as a modular reduction costs: 2 instructions).
+#define DEF_KERNEL_SEL(NAME, PRE, ASMSTR, OPS)                                         \
+__global__ void NAME(unsigned* out, unsigned seed) {                                   \
+  unsigned a0 = seed + threadIdx.x, a1 = a0 * 3u + 1, a2 = a0 * 5u + 2, a3 = a0 * 7u + 3; \
+  unsigned a4 = a0 * 11u + 4, a5 = a0 * 13u + 5, a6 = a0 * 17u + 6, a7 = a0 * 19u + 7;   \
+  unsigned b = seed * 2654435761u + 12345u + threadIdx.x, c = seed ^ 0x9e3779b9u;      \
+  unsigned long long mask = 0x5555333300ff0f0full * (seed | 1u);                       \
+  for (int it = 0; it < ITERS; ++it) {                                                 \
+    asm volatile(                                                                      \
+      PRE                                                                              \
+      ASMSTR("%0") ASMSTR("%1") ASMSTR("%2") ASMSTR("%3")                              \
+      ASMSTR("%4") ASMSTR("%5") ASMSTR("%6") ASMSTR("%7")                              \
+      ASMSTR("%0") ASMSTR("%1") ASMSTR("%2") ASMSTR("%3")                              \
+      ASMSTR("%4") ASMSTR("%5") ASMSTR("%6") ASMSTR("%7")                              \
+      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) \
+      : "v"(b), "v"(c), "s"(mask) : "vcc");                                            \
+  }                                                                                    \
+  out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;  \
+}
+#define I_CNDMASK_SGPR(A) "v_cndmask_b32_e64 " A ", " A ", %8, %10\n"
+#define I_CMP_CNDMASK(A)  "v_cmp_lt_u32 vcc, " A ", %9\nv_cndmask_b32 " A ", " A ", %8, vcc\n"
+DEF_KERNEL_SEL(k_cndmask_vccset, "s_mov_b64 vcc, %10\n", I_CNDMASK, 16)
+DEF_KERNEL_SEL(k_cndmask_sgpr, "", I_CNDMASK_SGPR, 16)
+DEF_KERNEL_SEL(k_cndmask_vcmp, "", I_CMP_CNDMASK, 32)
 DEF_KERNEL32(k_alignbit, I_ALIGNBIT)
 DEF_KERNEL32(k_bfe, I_BFE)
 DEF_KERNEL32(k_lshladd, I_LSHLADD)
@@ -166,7 +195,9 @@ int main() {
     {"v_add_u32", k_add}, {"v_add_u32(dep chain)", k_add_dep}, {"v_add_co_u32", k_addco}, {"v_addc_co_u32", k_addc},
     {"v_subb_co_u32", k_subb},
     {"v_add3_u32", k_add3}, {"v_lshl_add_u32", k_lshladd}, {"v_bfe_u32", k_bfe}, {"v_alignbit_b32", k_alignbit},
-    {"v_cndmask_b32", k_cndmask}, {"v_mov_b32_dpp", k_dpp},
+    {"v_cndmask_b32(vcc never set)", k_cndmask}, {"v_cndmask_b32(vcc by s_mov)", k_cndmask_vccset},
+    {"v_cndmask_b32_e64(sgpr mask)", k_cndmask_sgpr}, {"v_cmp+v_cndmask (x2 instr)", k_cndmask_vcmp},
+    {"v_mov_b32_dpp", k_dpp},
     {"v_mul_lo_u32", k_mullo}, {"v_mul_hi_u32", k_mulhi}, {"v_mad_u64_u32", k_mad64},
     {"v_mad_u64_u32(dep chain)", k_mad64_dep},
     {"v_mul_u32_u24", k_mul24}, {"v_mad_u32_u24", k_mad24}, {"v_mul_hi_u32_u24", k_mulhi24},
@@ -175,7 +206,7 @@ int main() {
     {"v_fma_f64", k_fma64}, {"v_mul_f64", k_mul64}, {"v_add_f64", k_add64}, {"v_rndne_f64", k_rnd64},
   };
   hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-  printf("%-28s %6s %12s %14s %16s\n", "instr", "w/SIMD", "ms", "ns/winstr/SIMD", "cyc@2.4GHz");
+  printf("%-30s %6s %12s %14s %16s\n", "instr", "w/SIMD", "ms", "ns/winstr/SIMD", "cyc@2.4GHz");
   for (auto& e : es) {
     for (int wps : {1, 2, 4, 8}) {
       // one block of 256 threads = 1 wave per SIMD on a CU; wps blocks per CU
@@ -186,9 +217,10 @@ int main() {
       e.k<<<blocks, 256>>>(out, 2);
       CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
       float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
-      double winstr_per_simd = (double)ITERS * UNROLL * wps;   // wave-instructions issued per SIMD
+      const bool two = std::string(e.name).find("x2 instr") != std::string::npos;
+      double winstr_per_simd = (double)ITERS * UNROLL * wps * (two ? 2 : 1);   // wave-instructions issued per SIMD
       double ns = ms * 1e6 / winstr_per_simd;
-      printf("%-28s %6d %12.4f %14.3f %16.2f\n", e.name, wps, ms, ns, ns * 2.4);
+      printf("%-30s %6d %12.4f %14.3f %16.2f\n", e.name, wps, ms, ns, ns * 2.4);
     }
   }
   return 0;
