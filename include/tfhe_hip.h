@@ -119,6 +119,20 @@ const char *tfhe_status_string(int status);
 int tfhe_load_bootstrapping_key(tfhe_context *ctx, const uint32_t *bsk, const uint32_t *ksk);
 int tfhe_load_bootstrapping_key_device(tfhe_context *ctx, const uint32_t *bsk, const uint32_t *ksk);
 
+/* Unrolled blind rotation (the crate only sketches it: notes/BMMP Bootstrapping.md:13-25).  Two key
+ * bits are consumed per step with three GGSWs per pair,
+ *   bsk_bmmp [n/2][3][(k+1)*l][k+1][N]:  GGSW(s_2j s_2j+1), GGSW(s_2j (1 - s_2j+1)), GGSW(s_2j+1 (1 - s_2j)),
+ *   acc += sum_{m<3} (X^{e_m} - 1) * external_product(bsk_bmmp[j][m], acc),  e = (a_2j + a_2j+1, a_2j, a_2j+1):
+ * half the decompositions and forward transforms for a 1.5x key.  Loading such a key puts the
+ * context into this mode (tfhe_bootstrap_batch, tfhe_blind_rotate_batch, the gates ... then run it);
+ * loading an ordinary key switches back.  NOT the reference's bootstrap(): same plaintext, different
+ * key material, different ciphertext bits (checked against oracle.bootstrap_bmmp instead).  Needs
+ * even n and N = 512 (TFHE_ERR_UNSUPPORTED otherwise). */
+int tfhe_load_bootstrapping_key_bmmp(tfhe_context *ctx, const uint32_t *bsk_bmmp, const uint32_t *ksk);
+int tfhe_load_bootstrapping_key_bmmp_device(tfhe_context *ctx, const uint32_t *bsk_bmmp, const uint32_t *ksk);
+/* 1 if the loaded key is a BMMP key */
+int tfhe_context_uses_bmmp(const tfhe_context *ctx);
+
 /* ---- bootstrap(): bootstrapping.rs:58-120 ------------------------------------------------- */
 /* lwe_in  [batch][n+1]   LweCiphertext.data (a_0..a_{n-1}, b)              (lwe.rs:110-115)
  * test_vector_poly [tv_count][N], tv_count = 1 (shared) or batch; un-encoded values < 2^log_p,
@@ -265,6 +279,14 @@ int tfhe_bootstrapping_key_gen(tfhe_context *ctx, const uint32_t *lwe_sk, const 
 int tfhe_bootstrapping_key_gen_device(tfhe_context *ctx, const uint32_t *lwe_sk,
                                       const uint32_t *glwe_sk, uint32_t *bsk, uint32_t *ksk,
                                       int load);
+/* The same for the unrolled blind rotation: bsk_bmmp [n/2][3][(k+1)*l][k+1][N] pre-filled like bsk; the three
+ * GGSWs of pair j encrypt s_2j s_2j+1, s_2j (1 - s_2j+1), s_2j+1 (1 - s_2j)
+ * (notes/BMMP Bootstrapping.md:22-24).  `load` installs the key (BMMP mode). */
+int tfhe_bootstrapping_key_gen_bmmp(tfhe_context *ctx, const uint32_t *lwe_sk, const uint32_t *glwe_sk,
+                                    uint32_t *bsk_bmmp, uint32_t *ksk, int load);
+int tfhe_bootstrapping_key_gen_bmmp_device(tfhe_context *ctx, const uint32_t *lwe_sk,
+                                           const uint32_t *glwe_sk, uint32_t *bsk_bmmp, uint32_t *ksk,
+                                           int load);
 
 /* ---- bootstrap order --------------------------------------------------------------
  * 0 (default): the reference's order, PBS then key switch (bootstrapping.rs:58-120): ciphertexts at

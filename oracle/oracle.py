@@ -375,6 +375,64 @@ def blind_rotate(params: Params, lwe_ct, bsk, test_vector_poly) -> np.ndarray:
     return acc
 
 
+# ---------------------------------------------------------------- notes/BMMP Bootstrapping.md
+def bmmp_messages(lwe_sk) -> np.ndarray:
+    """The GGSW messages of the unrolled blind rotation, three per pair of key bits
+    (notes/BMMP Bootstrapping.md:22-24): s s', s (1 - s'), s' (1 - s)."""
+    sk = _a(lwe_sk).astype(np.int64)
+    assert sk.size % 2 == 0
+    s0, s1 = sk[0::2], sk[1::2]
+    return np.stack([s0 * s1, s0 * (1 - s1), s1 * (1 - s0)], axis=1).reshape(-1).astype(np.uint32)
+
+
+def bmmp_bsk_shape(params: Params):
+    return (params.n // 2 * 3, params.R, params.k + 1, params.N)
+
+
+def blind_rotate_bmmp(params: Params, lwe_ct, bsk_bmmp, test_vector_poly) -> np.ndarray:
+    """notes/BMMP Bootstrapping.md:13-25 composed from the reference's own steps: with
+    X^{a s + a' s'} = s s' (X^{a+a'} - 1) + s (1 - s') (X^a - 1) + (1 - s) s' (X^{a'} - 1) + 1
+    one step is acc += sum_m (X^{e_m} - 1) * external_product(bk_{3j+m}, acc), e = (a+a', a, a');
+    external_product = ggsw.rs:132-161, the monomial products = glwe.rs:20-34, all sums wrapping u32.
+    bsk_bmmp [n/2*3][R][k+1][N]."""
+    lwe_ct, bsk, tv = _a(lwe_ct), _a(bsk_bmmp), _a(test_vector_poly)
+    assert params.n % 2 == 0 and bsk.shape == bmmp_bsk_shape(params)
+    two_n = 2 * params.N
+    a = switch_modulus(lwe_ct, 32, params.glwe_poly_degree + 1)
+    acc = np.zeros((params.k + 1, params.N), dtype=np.uint32)
+    acc[params.k] = (tv.astype(np.uint64) << np.uint64(32 - params.log_p - params.padding_bits)).astype(np.uint32)
+    acc = glwe_mul_monomial(acc, -int(a[params.n]))
+    for j in range(params.n // 2):
+        e = ((int(a[2 * j]) + int(a[2 * j + 1])) % two_n, int(a[2 * j]), int(a[2 * j + 1]))
+        prods = [external_product(params, bsk[3 * j + m], acc) for m in range(3)]
+        for m in range(3):
+            acc = (acc + glwe_mul_monomial(prods[m], e[m]) - prods[m]).astype(np.uint32)
+    return acc
+
+
+def bootstrap_bmmp(params: Params, lwe_ct, bsk_bmmp, ksk, test_vector_poly) -> np.ndarray:
+    """bootstrap() (bootstrapping.rs:58-120) with the unrolled blind rotation in place of the loop
+    :79-105: mod switch -> blind_rotate_bmmp -> sample_extract -> key_switch_lwe."""
+    acc = blind_rotate_bmmp(params, lwe_ct, bsk_bmmp, test_vector_poly)
+    return key_switch_lwe(sample_extract(params, acc, 0), params.big_n, params.n, params.ks, _a(ksk))
+
+
+def keygen_bmmp(params: Params, rng: "Rng"):
+    """-> (lwe_sk, glwe_sk, bsk_bmmp [n/2*3][R][k+1][N], ksk): bootstrapping_key_gen
+    (bootstrapping.rs:23-56) with the three product messages per key-bit pair in place of the bits."""
+    cp = params.to_c()
+    lwe_sk = np.zeros(params.n, dtype=np.uint32)
+    glwe_sk = np.zeros((params.k, params.N), dtype=np.uint32)
+    lib().orc_lwe_secret_key_random(C.byref(cp), C.byref(rng.c), _p(lwe_sk))
+    lib().orc_glwe_secret_key_random(C.byref(cp), C.byref(rng.c), _p(glwe_sk))
+    bsk = np.stack([encrypt_ggsw(params, glwe_sk, int(m), rng) for m in bmmp_messages(lwe_sk)])
+    # the key switching key is the ordinary one: any valid KSK from the flattened GLWE key to lwe_sk
+    samples = rng.uniform_u32(params.ksk_shape())
+    samples[:, params.n] = sample_gaussian(rng, params.lwe_std_dev, samples.shape[0])
+    ksk = generate_ksk_from_samples(glwe_sk.reshape(-1), lwe_sk, params.ks, samples)
+    return lwe_sk, glwe_sk, bsk, ksk
+
+
 # ---------------------------------------------------------------- test_vector.rs / boolean.rs
 def construct_test_from_lut(params: Params, lut) -> np.ndarray:
     lut = _a(lut)

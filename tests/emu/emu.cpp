@@ -148,6 +148,26 @@ void blind_rotate(const PbsParams& P, size_t batch, const u32* lwe, const u32* t
   });
 }
 
+// the unrolled blind rotation (pbs_wave.h::blind_rotate_bmmp_team); bsk: prepared [n/2][3] GGSWs
+template <class F, int LOGN, int K, int G>
+void blind_rotate_bmmp(const PbsParams& P, size_t batch, const u32* lwe, const u32* tv, size_t tv_stride,
+                       const typename F::elem* bsk, u32* out_glwe, u32* out_lwe) {
+  typedef typename F::elem elem;
+  constexpr int N = 1 << LOGN;
+  constexpr int E = NttShape<LOGN, G>::kE;
+  constexpr int T = NttShape<LOGN, G>::kThreads;
+  run_team<F>(LOGN, K + 1, G, [&](const HostWave<elem>& w) {
+    for (size_t b = 0; b < batch; ++b) {
+      blind_rotate_bmmp_team<F, LOGN, K, G>(w, P, lwe + b * (P.n + 1), tv + b * tv_stride, bsk);
+      if (out_glwe)
+        for (int r = 0; r < E; ++r)
+          out_glwe[(b * (K + 1) + w.group()) * N + r * T + w.tid()] = w.acc()[r * T + w.tid()];
+      if (out_lwe) sample_extract_team<LOGN, K, G>(w, out_lwe + b * ((size_t)K * N + 1));
+      w.team_sync();
+    }
+  });
+}
+
 template <class F, int LOGN, int K, int G>
 void ext_product(const PbsParams& P, const typename F::elem* ggsw, const u32* glwe, u32* out) {
   typedef typename F::elem elem;
@@ -249,6 +269,18 @@ double emu_fp_from_key_word(u32 w, int part) { return FpField::from_key_word(w, 
 
 int emu_bsk_prepare(int field, int logn, int g, size_t polys, const u32* src, void* dst) {
   DISPATCH_FIELD(field, DISPATCH_LOGN(logn, g, (bsk_prepare<FF, L, GG>(polys, src, (FF::elem*)dst))));
+  return 0;
+}
+
+// N = 512, one wave per polynomial, one exchange buffer (the shape the GPU library offers it for)
+int emu_blind_rotate_bmmp(int field, u32 n, u32 k, u32 log_p, u32 padding, u32 log_base, u32 levels, size_t batch,
+                          const u32* lwe, const u32* tv, size_t tv_stride, const void* bsk, u32* out_glwe,
+                          u32* out_lwe) {
+  PbsParams P = make_params(n, k, 9, log_p, padding, log_base, levels);
+  if (g_exchange_buffers != 1 || (n & 1u)) return 2;
+  if (k == 1) { DISPATCH_FIELD(field, (blind_rotate_bmmp<FF, 9, 1, 1>(P, batch, lwe, tv, tv_stride, (const FF::elem*)bsk, out_glwe, out_lwe));) }
+  else if (k == 2) { DISPATCH_FIELD(field, (blind_rotate_bmmp<FF, 9, 2, 1>(P, batch, lwe, tv, tv_stride, (const FF::elem*)bsk, out_glwe, out_lwe));) }
+  else return 1;
   return 0;
 }
 

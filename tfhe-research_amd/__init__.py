@@ -101,6 +101,10 @@ class TfheParams:
     def bsk_shape(self):
         return (self.n, self.R, self.k + 1, self.N)
 
+    def bsk_bmmp_shape(self):
+        """the unrolled (BMMP) key: three GGSWs per pair of key bits, flattened [n/2*3][R][k+1][N]"""
+        return (self.n // 2 * 3, self.R, self.k + 1, self.N)
+
     def ksk_shape(self):
         return (self.big_n * self.ks_decomposer.levels, self.n + 1)
 
@@ -420,6 +424,24 @@ class Context:
             bsk, ksk = _np(bsk), _np(ksk)
             assert bsk.shape == p.bsk_shape() and ksk.shape == p.ksk_shape()
             self._check(lib().tfhe_load_bootstrapping_key(self._h, _hp(bsk), _hp(ksk)))
+
+    def load_bootstrapping_key_bmmp(self, bsk_bmmp, ksk):
+        """Key of the unrolled blind rotation (notes/BMMP Bootstrapping.md): bsk_bmmp [n/2*3][R][k+1][N]
+        = GGSW(s s'), GGSW(s (1-s')), GGSW(s' (1-s)) per pair of key bits.  Bootstraps and gates then use
+        it; needs N = 512 and even n.  Same plaintexts as the reference's bootstrap, different bits."""
+        p = self.params
+        if _is_torch(bsk_bmmp):
+            self._bind_torch()
+            assert tuple(bsk_bmmp.shape) == p.bsk_bmmp_shape() and tuple(ksk.shape) == p.ksk_shape()
+            self._check(lib().tfhe_load_bootstrapping_key_bmmp_device(self._h, _dp(bsk_bmmp), _dp(ksk)))
+        else:
+            bsk_bmmp, ksk = _np(bsk_bmmp), _np(ksk)
+            assert bsk_bmmp.shape == p.bsk_bmmp_shape() and ksk.shape == p.ksk_shape()
+            self._check(lib().tfhe_load_bootstrapping_key_bmmp(self._h, _hp(bsk_bmmp), _hp(ksk)))
+
+    @property
+    def uses_bmmp(self) -> bool:
+        return bool(lib().tfhe_context_uses_bmmp(self._h))
 
     # -- hot path -------------------------------------------------------------------------------
     def _tv_count(self, tv, batch):
@@ -757,17 +779,35 @@ class Context:
                                                      C.c_int(int(load))))
         return bsk, ksk
 
+    def bootstrapping_key_gen_bmmp(self, lwe_sk, glwe_sk, bsk_samples, ksk_samples, load: bool = True):
+        """The BMMP key on pre-filled buffers: bsk_samples [n/2*3][R][k+1][N], ksk_samples as for
+        bootstrapping_key_gen -> (bsk_bmmp, ksk); `load` installs it.  Torch tensors in place."""
+        p = self.params
+        lsk, gsk = _np(lwe_sk).reshape(p.n), _np(glwe_sk).reshape(p.k, p.N)
+        if _is_torch(bsk_samples):
+            self._bind_torch()
+            assert tuple(bsk_samples.shape) == p.bsk_bmmp_shape() and tuple(ksk_samples.shape) == p.ksk_shape()
+            self._check(lib().tfhe_bootstrapping_key_gen_bmmp_device(self._h, _hp(lsk), _hp(gsk), _dp(bsk_samples),
+                                                                     _dp(ksk_samples), C.c_int(int(load))))
+            return bsk_samples, ksk_samples
+        bsk, ksk = _np(bsk_samples).copy(), _np(ksk_samples).copy()
+        assert bsk.shape == p.bsk_bmmp_shape() and ksk.shape == p.ksk_shape()
+        self._check(lib().tfhe_bootstrapping_key_gen_bmmp(self._h, _hp(lsk), _hp(gsk), _hp(bsk), _hp(ksk),
+                                                          C.c_int(int(load))))
+        return bsk, ksk
+
     # -- convenience on top of the encryption-side entry points ---------------------------------
     @staticmethod
     def _noise(rng, std_dev: float, shape) -> np.ndarray:
         """two-sided rounded Gaussian on the 32-bit torus (utils.rs:36-54 without the saturation)"""
         return (np.rint(rng.normal(0.0, std_dev * 2.0 ** 32, size=shape)).astype(np.int64) & 0xFFFFFFFF).astype(np.uint32)
 
-    def generate_keys(self, rng=None, load: bool = True):
+    def generate_keys(self, rng=None, load: bool = True, bmmp: bool = False):
         """LweSecretKey::random + GlweSecretKey::random + bootstrapping_key_gen (lwe.rs:53-60,
         glwe.rs:176-182, bootstrapping.rs:23-56): secrets, masks and errors are drawn here (the
         reference draws them with its `R: CryptoRng + RngCore`), the key material is completed on
-        the GPU and, with `load`, installed.  -> (lwe_sk [n], glwe_sk [k][N], bsk, ksk)
+        the GPU and, with `load`, installed.  -> (lwe_sk [n], glwe_sk [k][N], bsk, ksk).  bmmp=True
+        makes the key of the unrolled blind rotation instead (bsk [n/2*3][R][k+1][N]).
 
         Randomness: by default every draw comes from the operating system's CSPRNG (SystemRng over
         os.urandom).  `rng=` is a TEST HOOK for reproducible runs: a numpy Generator (PCG64 etc.)
@@ -778,11 +818,13 @@ class Context:
         rng = rng if rng is not None else SystemRng()
         lwe_sk = rng.integers(0, 2, size=p.n).astype(np.uint32)
         glwe_sk = rng.integers(0, 2, size=(p.k, p.N)).astype(np.uint32)
-        bsk = rng.integers(0, 1 << 32, size=p.bsk_shape(), dtype=np.uint64).astype(np.uint32)
-        bsk[:, :, p.k, :] = self._noise(rng, p.glwe_std_dev, (p.n, p.R, p.N))
+        shape = p.bsk_bmmp_shape() if bmmp else p.bsk_shape()
+        bsk = rng.integers(0, 1 << 32, size=shape, dtype=np.uint64).astype(np.uint32)
+        bsk[:, :, p.k, :] = self._noise(rng, p.glwe_std_dev, (shape[0], p.R, p.N))
         ksk = rng.integers(0, 1 << 32, size=p.ksk_shape(), dtype=np.uint64).astype(np.uint32)
         ksk[:, p.n] = self._noise(rng, p.lwe_std_dev, ksk.shape[0])
-        bsk, ksk = self.bootstrapping_key_gen(lwe_sk, glwe_sk, bsk, ksk, load=load)
+        gen = self.bootstrapping_key_gen_bmmp if bmmp else self.bootstrapping_key_gen
+        bsk, ksk = gen(lwe_sk, glwe_sk, bsk, ksk, load=load)
         return lwe_sk, glwe_sk, bsk, ksk
 
     def encrypt_bits(self, lwe_sk, messages, rng=None) -> np.ndarray:

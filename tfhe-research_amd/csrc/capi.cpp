@@ -36,6 +36,8 @@ struct tfhe_context {
   void* d_bsk = nullptr;      // prepared BSK [n][R][k+1][parts][N] (spectrum_slot order, x 1/N)
   u32* d_ksk = nullptr;       // [big_n*l_ks][n+1]
   bool have_key = false;
+  bool bmmp = false;          // the loaded key is a BMMP key: n/2 * 3 GGSWs (tfhe_load_bootstrapping_key_bmmp)
+  size_t bsk_ggsws = 0;       // GGSWs d_bsk was allocated for
   bool aligned = false;       // decomposer alignment (tfhe_context_set_decomposer_alignment)
   bool ks_first = false;      // bootstrap order (tfhe_context_set_bootstrap_order)
 
@@ -205,6 +207,15 @@ size_t io_words(const tfhe_context* ctx) {
   return (ctx->ks_first ? (size_t)ctx->big_n : (size_t)ctx->params.lwe_dimension) + 1;
 }
 
+// the blind rotation the loaded key calls for: bootstrapping.rs:79-105, or the unrolled loop of
+// notes/BMMP Bootstrapping.md with a BMMP key
+hipError_t enqueue_blind_rotate(tfhe_context* ctx, const u32* lwe_in, size_t batch, const u32* tv,
+                                size_t tv_count, u32* glwe_out, u32* lwe_extracted) {
+  auto fn = ctx->bmmp ? launch::blind_rotate_bmmp : launch::blind_rotate;
+  return fn(ctx->stream, ctx->field, ctx->pbs, ctx->d_tw, lwe_in, batch, tv, tv_count == 1 ? 0 : ctx->N,
+            ctx->d_bsk, glwe_out, lwe_extracted);
+}
+
 // d_lwe_big: [batch][k*N+1] scratch of the reference order (unused when the key switch comes first)
 int enqueue_bootstrap(tfhe_context* ctx, const u32* d_lwe_in, size_t batch, const u32* d_tv,
                       size_t tv_count, u32* d_lwe_big, u32* d_lwe_out) {
@@ -219,8 +230,7 @@ int enqueue_bootstrap(tfhe_context* ctx, const u32* d_lwe_in, size_t batch, cons
     br_out = d_lwe_out;
   }
   if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-  HIP_TRY(ctx, launch::blind_rotate(ctx->stream, ctx->field, ctx->pbs, ctx->d_tw, br_in, batch, d_tv,
-                                    tv_count == 1 ? 0 : ctx->N, ctx->d_bsk, nullptr, br_out));
+  HIP_TRY(ctx, enqueue_blind_rotate(ctx, br_in, batch, d_tv, tv_count, nullptr, br_out));
   if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
   if (!ctx->ks_first) {
     if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
@@ -534,12 +544,34 @@ int tfhe_last_kernel_ms(tfhe_context* ctx, float* blind_rotate_ms, float* key_sw
 }
 
 // ---------------------------------------------------------------------------------- keys
+// GGSWs of a bootstrapping key: one per key bit, or three per pair of key bits (BMMP)
+static size_t key_ggsws(const tfhe_context* ctx, bool bmmp) {
+  const size_t n = ctx->params.lwe_dimension;
+  return bmmp ? n / 2 * 3 : n;
+}
+
+static int check_bmmp(tfhe_context* ctx) {
+  if (!launch::shape_supported_bmmp(ctx->pbs.log_n, ctx->pbs.k) || (ctx->params.lwe_dimension & 1u))
+    return fail(ctx, TFHE_ERR_UNSUPPORTED, "the unrolled (BMMP) blind rotation needs N = 512 and an even lwe_dimension");
+  return TFHE_OK;
+}
+
 static int load_key_common(tfhe_context* ctx, const u32* d_bsk_raw, const u32* d_ksk_raw,
-                           bool ksk_needs_copy) {
-  const size_t bsk_polys = (size_t)ctx->params.lwe_dimension * ctx->R * (ctx->params.glwe_dimension + 1);
+                           bool ksk_needs_copy, bool bmmp = false) {
+  const size_t ggsws = key_ggsws(ctx, bmmp);
+  const size_t bsk_polys = ggsws * ctx->R * (ctx->params.glwe_dimension + 1);
   const size_t ksk_words = (size_t)ctx->big_n * ctx->ks.levels * ((size_t)ctx->params.lwe_dimension + 1);
-  if (!ctx->d_bsk)
+  if (ctx->d_bsk && ctx->bsk_ggsws != ggsws) {  // the other kind of key was loaded before
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->have_key = false;
+    hipError_t e = hipFree(ctx->d_bsk);
+    ctx->d_bsk = nullptr;
+    if (e != hipSuccess) return hip_fail(ctx, e, "hipFree(bsk)");
+  }
+  if (!ctx->d_bsk) {
     HIP_TRY(ctx, hipMalloc(&ctx->d_bsk, bsk_polys * ctx->parts * ctx->N * sizeof(u64)));
+    ctx->bsk_ggsws = ggsws;
+  }
   if (!ctx->d_ksk)
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_ksk), ksk_words * sizeof(u32)));
   HIP_TRY(ctx, launch::bsk_prepare(ctx->stream, ctx->field, ctx->pbs.log_n, ctx->d_tw, d_bsk_raw, bsk_polys, ctx->d_bsk));
@@ -548,14 +580,13 @@ static int load_key_common(tfhe_context* ctx, const u32* d_bsk_raw, const u32* d
                                 hipMemcpyDeviceToDevice, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   ctx->have_key = true;
+  ctx->bmmp = bmmp;
   return TFHE_OK;
 }
 
-int tfhe_load_bootstrapping_key(tfhe_context* ctx, const uint32_t* bsk, const uint32_t* ksk) {
-  int st = check_ctx(ctx);
-  if (st) return st;
+static int load_key_host(tfhe_context* ctx, const uint32_t* bsk, const uint32_t* ksk, bool bmmp) {
   if (!bsk || !ksk) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null key pointer");
-  const size_t bsk_words = (size_t)ctx->params.lwe_dimension * ggsw_words(ctx);
+  const size_t bsk_words = key_ggsws(ctx, bmmp) * ggsw_words(ctx);
   const size_t ksk_words = (size_t)ctx->big_n * ctx->ks.levels * ((size_t)ctx->params.lwe_dimension + 1);
   u32* d_raw = nullptr;
   HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d_raw), bsk_words * sizeof(u32)));
@@ -567,9 +598,15 @@ int tfhe_load_bootstrapping_key(tfhe_context* ctx, const uint32_t* bsk, const ui
     (void)hipFree(d_raw);
     return hip_fail(ctx, e, "key upload");
   }
-  st = load_key_common(ctx, d_raw, nullptr, false);
+  int st = load_key_common(ctx, d_raw, nullptr, false, bmmp);
   (void)hipFree(d_raw);
   return st;
+}
+
+int tfhe_load_bootstrapping_key(tfhe_context* ctx, const uint32_t* bsk, const uint32_t* ksk) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  return load_key_host(ctx, bsk, ksk, false);
 }
 
 int tfhe_load_bootstrapping_key_device(tfhe_context* ctx, const uint32_t* bsk, const uint32_t* ksk) {
@@ -578,6 +615,23 @@ int tfhe_load_bootstrapping_key_device(tfhe_context* ctx, const uint32_t* bsk, c
   if (!bsk || !ksk) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null key pointer");
   return load_key_common(ctx, bsk, ksk, true);
 }
+
+int tfhe_load_bootstrapping_key_bmmp(tfhe_context* ctx, const uint32_t* bsk_bmmp, const uint32_t* ksk) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  if ((st = check_bmmp(ctx))) return st;
+  return load_key_host(ctx, bsk_bmmp, ksk, true);
+}
+
+int tfhe_load_bootstrapping_key_bmmp_device(tfhe_context* ctx, const uint32_t* bsk_bmmp, const uint32_t* ksk) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  if ((st = check_bmmp(ctx))) return st;
+  if (!bsk_bmmp || !ksk) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null key pointer");
+  return load_key_common(ctx, bsk_bmmp, ksk, true, true);
+}
+
+int tfhe_context_uses_bmmp(const tfhe_context* ctx) { return ctx && ctx->have_key && ctx->bmmp ? 1 : 0; }
 
 // ---------------------------------------------------------------------------------- bootstrap
 int tfhe_bootstrap_batch_device(tfhe_context* ctx, const uint32_t* lwe_in, size_t batch,
@@ -615,8 +669,7 @@ int tfhe_blind_rotate_batch_device(tfhe_context* ctx, const uint32_t* lwe_in, si
   if ((st = check_batch_args(ctx, lwe_in, tv, glwe_out, batch, tv_count))) return st;
   if (!ctx->have_key) return fail(ctx, TFHE_ERR_NO_KEY, "load the bootstrapping key first");
   if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-  HIP_TRY(ctx, launch::blind_rotate(ctx->stream, ctx->field, ctx->pbs, ctx->d_tw, lwe_in, batch, tv,
-                                    tv_count == 1 ? 0 : ctx->N, ctx->d_bsk, glwe_out, nullptr));
+  HIP_TRY(ctx, enqueue_blind_rotate(ctx, lwe_in, batch, tv, tv_count, glwe_out, nullptr));
   if (ctx->timing) {
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     ctx->ev_valid_br = true;
@@ -1124,6 +1177,60 @@ int tfhe_bootstrapping_key_gen(tfhe_context* ctx, const uint32_t* lwe_sk, const 
   if (st == TFHE_OK) {
     e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess) e = hipMemcpy(bsk, d_bsk, bsk_words * sizeof(u32), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(ksk, d_ksk, ksk_words * sizeof(u32), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) st = hip_fail(ctx, e, "key download");
+  }
+  if (d_bsk) (void)hipFree(d_bsk);
+  if (d_ksk) (void)hipFree(d_ksk);
+  return st;
+}
+
+// notes/BMMP Bootstrapping.md:22-24: the three GGSW messages of key-bit pair j
+static std::vector<u32> bmmp_messages(const u32* lwe_sk, size_t n) {
+  std::vector<u32> m(n / 2 * 3);
+  for (size_t j = 0; j < n / 2; ++j) {
+    const u32 s0 = lwe_sk[2 * j], s1 = lwe_sk[2 * j + 1];
+    m[3 * j + 0] = s0 * s1;
+    m[3 * j + 1] = s0 * (1u - s1);
+    m[3 * j + 2] = s1 * (1u - s0);
+  }
+  return m;
+}
+
+int tfhe_bootstrapping_key_gen_bmmp_device(tfhe_context* ctx, const uint32_t* lwe_sk, const uint32_t* glwe_sk,
+                                           uint32_t* bsk_bmmp, uint32_t* ksk, int load) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  if (!lwe_sk || !glwe_sk || !bsk_bmmp || !ksk) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer");
+  if ((st = check_bmmp(ctx))) return st;
+  const size_t n = ctx->params.lwe_dimension;
+  if ((st = check_binary(ctx, lwe_sk, n, "lwe secret key"))) return st;
+  const std::vector<u32> messages = bmmp_messages(lwe_sk, n);
+  if ((st = tfhe_ggsw_encrypt_batch_device(ctx, glwe_sk, messages.data(), bsk_bmmp, messages.size()))) return st;
+  if ((st = ksk_gen_device(ctx, glwe_sk, ctx->big_n, lwe_sk, n, ksk))) return st;
+  // `messages` is pageable host memory: the async copy inside has staged it before returning
+  if (load) return load_key_common(ctx, bsk_bmmp, ksk, true, true);
+  return TFHE_OK;
+}
+
+int tfhe_bootstrapping_key_gen_bmmp(tfhe_context* ctx, const uint32_t* lwe_sk, const uint32_t* glwe_sk,
+                                    uint32_t* bsk_bmmp, uint32_t* ksk, int load) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  if (!lwe_sk || !glwe_sk || !bsk_bmmp || !ksk) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer");
+  if ((st = check_bmmp(ctx))) return st;
+  const size_t bsk_words = key_ggsws(ctx, true) * ggsw_words(ctx);
+  const size_t ksk_words = (size_t)ctx->big_n * ctx->ks.levels * ((size_t)ctx->params.lwe_dimension + 1);
+  u32 *d_bsk = nullptr, *d_ksk = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_bsk), bsk_words * sizeof(u32));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_ksk), ksk_words * sizeof(u32));
+  if (e == hipSuccess) e = hipMemcpy(d_bsk, bsk_bmmp, bsk_words * sizeof(u32), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_ksk, ksk, ksk_words * sizeof(u32), hipMemcpyHostToDevice);
+  st = (e == hipSuccess) ? tfhe_bootstrapping_key_gen_bmmp_device(ctx, lwe_sk, glwe_sk, d_bsk, d_ksk, load)
+                         : hip_fail(ctx, e, "key buffers");
+  if (st == TFHE_OK) {
+    e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(bsk_bmmp, d_bsk, bsk_words * sizeof(u32), hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(ksk, d_ksk, ksk_words * sizeof(u32), hipMemcpyDeviceToHost);
     if (e != hipSuccess) st = hip_fail(ctx, e, "key download");
   }

@@ -203,6 +203,35 @@ blind_rotate_kernel(PbsParams P, const typename F::elem* __restrict__ tw,
   if (lwe_extracted) sample_extract_team<LOGN, K, G>(w, lwe_extracted + sample * ((size_t)K * N + 1));
 }
 
+// unrolled blind rotation (two key bits per step, pbs_wave.h::blind_rotate_bmmp_team); offered where a
+// lane holds 8 elements per array and one wave owns a polynomial: N = 512
+#ifndef TFHE_BMMP_MIN_WAVES
+#define TFHE_BMMP_MIN_WAVES 3
+#endif
+template <class F, int LOGN, int K>
+__global__ void __launch_bounds__((TeamCfg<LOGN, K>::kThreads), TFHE_BMMP_MIN_WAVES)
+blind_rotate_bmmp_kernel(PbsParams P, const typename F::elem* __restrict__ tw,
+                         const u32* __restrict__ lwe_in, size_t batch, const u32* __restrict__ tv,
+                         size_t tv_stride, const typename F::elem* __restrict__ bsk,
+                         u32* __restrict__ glwe_out, u32* __restrict__ lwe_extracted) {
+  using C = TeamCfg<LOGN, K>;
+  constexpr int N = C::N;
+  constexpr int G = C::G;
+  constexpr int E = NttShape<LOGN, G>::kE;
+  constexpr int T = NttShape<LOGN, G>::kThreads;
+  static_assert(G == 1 && C::EXB == 1, "one wave per polynomial, one exchange buffer");
+  auto w = make_wave<F, LOGN, K>(g_smem, tw);
+  const size_t sample = blockIdx.x;
+  blind_rotate_bmmp_team<F, LOGN, K, G>(w, P, lwe_in + sample * (P.n + 1), tv + sample * tv_stride, bsk);
+  const int tid = w.tid();
+  if (glwe_out) {
+    u32* dst = glwe_out + (sample * (size_t)(K + 1) + w.group()) * N;
+#pragma unroll
+    for (int r = 0; r < E; ++r) dst[r * T + tid] = w.acc()[r * T + tid];
+  }
+  if (lwe_extracted) sample_extract_team<LOGN, K, G>(w, lwe_extracted + sample * ((size_t)K * N + 1));
+}
+
 // ------------------------------------------------------------------------------ external product
 // Persistent grid: a team takes samples blockIdx.x, blockIdx.x + gridDim.x, ... so the twiddle
 // table is staged into LDS once per team instead of once per sample (the launcher sizes the grid to
@@ -587,6 +616,26 @@ hipError_t launch_blind_rotate(hipStream_t s, const PbsParams& P, const void* tw
 }
 
 template <class F, int LOGN, int K>
+hipError_t launch_blind_rotate_bmmp(hipStream_t s, const PbsParams& P, const void* tw_v, const u32* lwe_in,
+                                    size_t batch, const u32* tv, size_t tv_stride, const void* bsk_v,
+                                    u32* glwe_out, u32* lwe_extracted) {
+  if constexpr (LOGN != 9) {
+    return hipErrorInvalidValue;  // shape_supported_bmmp() keeps callers away
+  } else {
+    using C = TeamCfg<LOGN, K>;
+    auto tw = static_cast<const typename F::elem*>(tw_v);
+    auto bsk = static_cast<const typename F::elem*>(bsk_v);
+    auto kern = blind_rotate_bmmp_kernel<F, LOGN, K>;
+    static std::atomic<unsigned long long> lds_done{0};
+    hipError_t e = allow_lds(kern, C::kLds, lds_done);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(C::kThreads), C::kLds, s, P, tw, lwe_in, batch,
+                       tv, tv_stride, bsk, glwe_out, lwe_extracted);
+    return hipGetLastError();
+  }
+}
+
+template <class F, int LOGN, int K>
 hipError_t launch_external_product(hipStream_t s, const PbsParams& P, const void* tw_v,
                                    const void* ggsw_v, size_t ggsw_stride_words, const u32* glwe_in,
                                    u32* ct1_inout, const u32* cmux_ct0, size_t batch, u32* glwe_out) {
@@ -659,6 +708,8 @@ namespace launch {
 
 bool shape_supported(u32 log_n, u32 k) { return log_n >= 9 && log_n <= 11 && (k == 1 || k == 2); }
 
+bool shape_supported_bmmp(u32 log_n, u32 k) { return log_n == 9 && (k == 1 || k == 2); }
+
 int field_parts(int field) { return (field == kFieldGoldilocks || field == kFieldFp49) ? 1 : 2; }
 
 // (field, log_n, k) -> template instantiation.  TFHE_DEV_CFG2_ONLY builds just the BASELINE cfg2
@@ -707,11 +758,18 @@ int field_parts(int field) { return (field == kFieldGoldilocks || field == kFiel
   }
 #endif
 
-#if defined(TFHE_DEV_FIELD_FP_ONLY)  // dev builds: only the fp64-p42 field (fast iteration on the kernels)
+#if defined(TFHE_DEV_FIELD_FP_ONLY) || defined(TFHE_DEV_FIELD_FP49_ONLY)  // dev builds: one field (fast iteration)
+#if defined(TFHE_DEV_FIELD_FP49_ONLY)
+#define TFHE_DEV_FIELD_ID kFieldFp49
+#define TFHE_DEV_FIELD_T Fp49Field
+#else
+#define TFHE_DEV_FIELD_ID kFieldFp64
+#define TFHE_DEV_FIELD_T FpField
+#endif
 #define TFHE_DISPATCH_FIELD(field, BODY)                                      \
   do {                                                                        \
-    if ((field) == kFieldFp64) {                                              \
-      typedef FpField FF;                                                     \
+    if ((field) == TFHE_DEV_FIELD_ID) {                                       \
+      typedef TFHE_DEV_FIELD_T FF;                                            \
       BODY                                                                    \
     }                                                                         \
     return hipErrorInvalidValue;                                              \
@@ -747,6 +805,15 @@ hipError_t blind_rotate(hipStream_t s, int field, const PbsParams& P, const void
   TFHE_DISPATCH_FIELD(field, TFHE_DISPATCH_LOGN_K(P.log_n, P.k,
                       (launch_blind_rotate<FF, LL, KK>(s, P, tw, lwe_in, batch, tv, tv_stride, bsk,
                                                        glwe_out, lwe_extracted))));
+}
+
+hipError_t blind_rotate_bmmp(hipStream_t s, int field, const PbsParams& P, const void* tw,
+                             const u32* lwe_in, size_t batch, const u32* tv, size_t tv_stride,
+                             const void* bsk, u32* glwe_out, u32* lwe_extracted) {
+  if (!shape_supported_bmmp(P.log_n, P.k) || (P.n & 1u)) return hipErrorInvalidValue;
+  TFHE_DISPATCH_FIELD(field, TFHE_DISPATCH_LOGN_K(P.log_n, P.k,
+                      (launch_blind_rotate_bmmp<FF, LL, KK>(s, P, tw, lwe_in, batch, tv, tv_stride, bsk,
+                                                            glwe_out, lwe_extracted))));
 }
 
 hipError_t external_product(hipStream_t s, int field, const PbsParams& P, const void* tw,

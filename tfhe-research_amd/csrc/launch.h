@@ -29,6 +29,13 @@ hipError_t blind_rotate(hipStream_t s, int field, const PbsParams& P, const void
                         const u32* lwe_in, size_t batch, const u32* tv, size_t tv_stride,
                         const void* bsk, u32* glwe_out, u32* lwe_extracted);
 
+// The unrolled blind rotation of notes/BMMP Bootstrapping.md (two key bits per step): bsk holds
+// n/2 * 3 prepared GGSWs (pbs_wave.h::blind_rotate_bmmp_team); n even, shape_supported_bmmp only.
+bool shape_supported_bmmp(u32 log_n, u32 k);
+hipError_t blind_rotate_bmmp(hipStream_t s, int field, const PbsParams& P, const void* tw,
+                             const u32* lwe_in, size_t batch, const u32* tv, size_t tv_stride,
+                             const void* bsk, u32* glwe_out, u32* lwe_extracted);
+
 // out = external_product(ggsw[g], glwe[b]) (+ ct0 for the CMUX form).
 //   cmux_ct0 == nullptr : src = glwe_in
 //   cmux_ct0 != nullptr : src = ct1 - ct0 where ct1 = glwe_inout_ct1 (overwritten with the

@@ -131,10 +131,16 @@ TFHE_HD u32 monomial_coeff(const u32* poly, int j, u32 m) {
 //              pre-scaled by N^-1 (so the unscaled inverse NTT lands on the true product)
 //   out(j, value mod 2^32) is called once per coefficient of output polynomial c.
 // Every wave of the team must call this the same number of times (it contains barriers).
+//
+// external_product_team_keys multiplies ONE GLWE operand with KEYS prepared GGSWs (ggsw, ggsw +
+// ggsw_words, ...): the decomposition and the forward transforms are shared, only the
+// multiply-accumulate and the inverse transforms are per key (the unrolled blind rotation of
+// notes/BMMP Bootstrapping.md needs three products of the same accumulator).  out(m, j, value) is
+// called for key m = 0 .. KEYS-1 in turn, end_of_key(m) once after the last coefficient of key m.
 // ---------------------------------------------------------------------------------------------
-template <class F, int LOGN, int K, int G, class Ctx, class Src, class Out>
-TFHE_HD void external_product_team(const Ctx& c, const PbsParams& P, const typename F::elem* ggsw,
-                                   Src src, Out out) {
+template <class F, int LOGN, int K, int G, int KEYS, class Ctx, class Src, class Out, class EndKey>
+TFHE_HD void external_product_team_keys(const Ctx& c, const PbsParams& P, const typename F::elem* ggsw,
+                                        size_t ggsw_words, Src src, Out out, EndKey end_of_key) {
   typedef typename F::elem elem;
   constexpr int E = NttShape<LOGN, G>::kE;
   constexpr int T = NttShape<LOGN, G>::kThreads;  // threads per polynomial
@@ -142,13 +148,15 @@ TFHE_HD void external_product_team(const Ctx& c, const PbsParams& P, const typen
   constexpr int PARTS = F::kParts;
   const int lane = c.tid();   // thread index inside my polynomial's group of G waves
   const int me = c.group();   // polynomial / output column owned by my group
-  constexpr bool SPLIT = F::template split_accum<E>();
+  // (h, l) accumulator pairs only for a single key: with several keys the second set does not fit
+  constexpr bool SPLIT = F::template split_accum<E>() && KEYS == 1;
+  constexpr int ACCS = KEYS * PARTS;  // accumulator a = m * PARTS + q: key m, key part q
 
-  elem accum[PARTS][E];
+  elem accum[ACCS][E];
   // second accumulator set of fields that add up unreduced (h, l) product pairs (F::split_accum)
-  elem accum_lo[SPLIT ? PARTS : 1][SPLIT ? E : 1];
+  elem accum_lo[SPLIT ? ACCS : 1][SPLIT ? E : 1];
 #pragma unroll
-  for (int q = 0; q < PARTS; ++q)
+  for (int q = 0; q < ACCS; ++q)
 #pragma unroll
     for (int r = 0; r < E; ++r) {
       accum[q][r] = SPLIT ? F::accum_init() : F::zero();
@@ -172,12 +180,13 @@ TFHE_HD void external_product_team(const Ctx& c, const PbsParams& P, const typen
 #ifndef TFHE_CHUNK
 #define TFHE_CHUNK 8
 #endif
-  constexpr int TILES = (K + 1) * PARTS;
+  constexpr int TILES = (K + 1) * ACCS;
   constexpr int CH = E < TFHE_CHUNK ? E : TFHE_CHUNK;
   constexpr int CHUNKS = TILES * (E / CH);
-  auto tile_ptr = [&](u32 level, int idx) -> const elem* {
-    const int s = idx / PARTS, q = idx % PARTS;
-    return ggsw + (((size_t)(s * P.levels + level) * (K + 1) + me) * PARTS + q) * N;
+  // tile of source polynomial s and accumulator a = (key m, part q)
+  auto tile_ptr = [&](u32 level, int s, int a) -> const elem* {
+    const int m = a / PARTS, q = a % PARTS;
+    return ggsw + (size_t)m * ggsw_words + (((size_t)(s * P.levels + level) * (K + 1) + me) * PARTS + q) * N;
   };
   // Spectrum exchange through LDS.  With ONE buffer per group a level needs two team barriers
   // (publish -> consume -> the next transform reuses the buffer).  With TWO buffers level t works in
@@ -193,7 +202,7 @@ TFHE_HD void external_product_team(const Ctx& c, const PbsParams& P, const typen
     const u32 shift = P.first_shift + P.log_base * t;
     const Ctx cl = c.with_exchange_buffer(two ? (int)(t & 1u) : 0);
     {
-      const elem* tile = tile_ptr(level, 0);
+      const elem* tile = tile_ptr(level, 0, 0);
 #pragma unroll
       for (int r = 0; r < CH; ++r) kbuf[0][r] = tile[spectrum_slot<LOGN, G>(lane, r)];
     }
@@ -218,17 +227,18 @@ TFHE_HD void external_product_team(const Ctx& c, const PbsParams& P, const typen
       for (int r = 0; r < E; ++r) mine[exchange_slot<LOGN, G>(lane, r)] = work[r];
     }
     c.team_sync();
-    // chunk order: source polynomial s, then the CH-register piece of its spectrum, then the key
-    // part q -- so that a piece of the digit spectrum is read from LDS once and used for all parts
+    // chunk order: source polynomial s, then the CH-register piece of its spectrum, then the
+    // accumulator (key, key part) -- so that a piece of the digit spectrum is read from LDS once and
+    // used for every key and part
     elem d[CH];
     static_for<0, CHUNKS>([&](auto ci_c) {
       constexpr int ci = decltype(ci_c)::value;
       constexpr int PIECES = E / CH;
-      constexpr int q = ci % PARTS, r0 = ((ci / PARTS) % PIECES) * CH, s = ci / (PARTS * PIECES);
+      constexpr int q = ci % ACCS, r0 = ((ci / ACCS) % PIECES) * CH, s = ci / (ACCS * PIECES);
       constexpr int cur = ci & 1, nxt = cur ^ 1;
       if constexpr (ci + 1 < CHUNKS) {
-        constexpr int nq = (ci + 1) % PARTS, nr0 = (((ci + 1) / PARTS) % PIECES) * CH, ns = (ci + 1) / (PARTS * PIECES);
-        const elem* tile = tile_ptr(level, ns * PARTS + nq);
+        constexpr int nq = (ci + 1) % ACCS, nr0 = (((ci + 1) / ACCS) % PIECES) * CH, ns = (ci + 1) / (ACCS * PIECES);
+        const elem* tile = tile_ptr(level, ns, nq);
 #pragma unroll
         for (int r = 0; r < CH; ++r) kbuf[nxt][r] = tile[spectrum_slot<LOGN, G>(lane, nr0 + r)];
       }
@@ -250,25 +260,37 @@ TFHE_HD void external_product_team(const Ctx& c, const PbsParams& P, const typen
   }
 
   const Ctx ci = c.with_exchange_buffer(two ? (int)(P.levels & 1u) : 0);
-  static_for<0, PARTS>([&](auto part_c) {
-    constexpr int q = decltype(part_c)::value;
+  static_for<0, KEYS>([&](auto key_c) {
+    constexpr int m = decltype(key_c)::value;
+    static_for<0, PARTS>([&](auto part_c) {
+      constexpr int q = m * PARTS + decltype(part_c)::value;
 #pragma unroll
-    for (int r = 0; r < E; ++r)
-      accum[q][r] = SPLIT ? F::mac_finish(accum[q][r], accum_lo[SPLIT ? q : 0][SPLIT ? r : 0])
-                                   : F::before_inverse(accum[q][r]);
-    ntt_inverse<F, LOGN, G>(ci, accum[q]);
+      for (int r = 0; r < E; ++r)
+        accum[q][r] = SPLIT ? F::mac_finish(accum[q][r], accum_lo[SPLIT ? q : 0][SPLIT ? r : 0])
+                            : F::before_inverse(accum[q][r]);
+      ntt_inverse<F, LOGN, G>(ci, accum[q]);
+    });
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+      elem parts[PARTS];
+#pragma unroll
+      for (int q = 0; q < PARTS; ++q) parts[q] = accum[m * PARTS + q][r];
+      out(m, r * T + lane, F::finish(parts));
+    }
+    end_of_key(m);
   });
-#pragma unroll
-  for (int r = 0; r < E; ++r) {
-    elem parts[PARTS];
-#pragma unroll
-    for (int q = 0; q < PARTS; ++q) parts[q] = accum[q][r];
-    out(r * T + lane, F::finish(parts));
-  }
   // two buffers: the MAC reads of the last level must be over before a following product (or any
   // other user of the buffers) writes buffer 0; this barrier also orders the out() stores of the
   // whole team.  One buffer: the last level already ended with a barrier.
   if (two) c.team_sync();
+}
+
+// one GGSW (ggsw.rs:132-161)
+template <class F, int LOGN, int K, int G, class Ctx, class Src, class Out>
+TFHE_HD void external_product_team(const Ctx& c, const PbsParams& P, const typename F::elem* ggsw,
+                                   Src src, Out out) {
+  external_product_team_keys<F, LOGN, K, G, 1>(
+      c, P, ggsw, 0, src, [&](int, int j, u32 value) { out(j, value); }, [](int) {});
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -319,6 +341,72 @@ TFHE_HD void blind_rotate_team(const Ctx& c, const PbsParams& P, const u32* lwe 
     external_product_team<F, LOGN, K, G>(c, P, bsk + (size_t)i * ggsw_words, src, out);
     // G > 1: the other waves of my group read what I just wrote (with two exchange buffers the
     // product already ended with a team barrier)
+    if (c.exchange_buffers() != 2) c.poly_sync();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Unrolled blind rotation (notes/BMMP Bootstrapping.md:13-25): two key bits per step.  With
+//   X^{a s + a' s'} = s s' (X^{a+a'} - 1) + s (1 - s') (X^a - 1) + (1 - s) s' (X^{a'} - 1) + 1
+// one step is   acc += sum_{m<3} (X^{e_m} - 1) * (BK_{3j+m} [x] acc)   with e = (a+a', a, a') and the
+// three GGSW encryptions BK_{3j} = s_{2j} s_{2j+1}, BK_{3j+1} = s_{2j} (1 - s_{2j+1}),
+// BK_{3j+2} = s_{2j+1} (1 - s_{2j}): n/2 decompositions and n/2 * levels forward transforms instead of
+// n and n * levels, against 1.5x the multiply-accumulates and inverse transforms and a 1.5x key.
+// The three products share the digits of acc (external_product_team_keys); each one is lifted on
+// its own and the monomial factor is applied in the coefficient domain -- an index rotation of the
+// staged product (my own transpose buffer: free once the inverse transforms are done and private
+// until I publish again) -- so every value is an ordinary external product within the field's bound
+// and the wrapping u32 sums are exact.  n must be even.  Not the reference's bootstrap(): the key
+// material differs, so the output bits differ from it (same plaintext); the oracle twin is
+// oracle.bootstrap_bmmp.
+// ---------------------------------------------------------------------------------------------
+template <class F, int LOGN, int K, int G, class Ctx>
+TFHE_HD void blind_rotate_bmmp_team(const Ctx& c, const PbsParams& P, const u32* lwe /* n+1 */,
+                                    const u32* tv /* N, un-encoded */,
+                                    const typename F::elem* bsk /* prepared [n/2][3] GGSWs */) {
+  constexpr int E = NttShape<LOGN, G>::kE;
+  constexpr int T = NttShape<LOGN, G>::kThreads;
+  constexpr int N = 1 << LOGN;
+  const int lane = c.tid();
+  const int me = c.group();
+  u32* acc = c.acc();
+  {
+    const u32 b_tilde = switch_modulus_2n(lwe[P.n], LOGN);
+    const u32 m = (2u * N - b_tilde) & (2u * N - 1u);
+    const int deg = (int)(m & (N - 1));
+    const u32 flip = (m >> LOGN) & 1u;
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+      const int j = r * T + lane;
+      u32 val = 0;
+      if (me == K) {
+        const u32 t = tv[(j - deg) & (N - 1)] << P.tv_shift;
+        val = (flip ^ (u32)(j < deg)) ? (0u - t) : t;
+      }
+      acc[j] = val;
+    }
+    c.poly_sync();
+  }
+  const size_t ggsw_words = (size_t)(K + 1) * P.levels * (K + 1) * F::kParts * N;
+  u32* stage = reinterpret_cast<u32*>(c.scratch());  // N u32 of my group's transpose buffer
+#pragma unroll 1
+  for (u32 pair = 0; pair < P.n / 2; ++pair) {
+    const u32 a0 = c.uniform(switch_modulus_2n(lwe[2 * pair], LOGN));
+    const u32 a1 = c.uniform(switch_modulus_2n(lwe[2 * pair + 1], LOGN));
+    const u32 e[3] = {(a0 + a1) & (2u * N - 1u), a0, a1};
+    auto src = [&](int j) -> u32 { return acc[j]; };
+    auto out = [&](int, int j, u32 value) { stage[j] = value; };
+    auto end_of_key = [&](int m) {
+      c.poly_sync();  // the staged product is complete (G > 1: across the group's waves)
+#pragma unroll
+      for (int r = 0; r < E; ++r) {
+        const int j = r * T + lane;
+        acc[j] += monomial_coeff<LOGN>(stage, j, e[m]) - stage[j];
+      }
+      c.poly_sync();  // before the next inverse transform reuses the buffer
+    };
+    external_product_team_keys<F, LOGN, K, G, 3>(c, P, bsk + (size_t)pair * 3 * ggsw_words, ggsw_words, src, out,
+                                                 end_of_key);
     if (c.exchange_buffers() != 2) c.poly_sync();
   }
 }
