@@ -38,3 +38,24 @@ def test_not_mux_lut_and_levels():
         assert w[sel3] == w[mx]            # the same multiplexer as one 3-input LUT
         assert w[x] == w[n] ^ w[mx]
     assert c.levels() == [[0, 1, 2], [3]]
+
+
+def test_system_rng_is_the_default_source_of_key_material():
+    """generate_keys / encrypt_bits draw from the OS CSPRNG unless the test hook rng= is passed (the
+    reference requires R: CryptoRng + RngCore, lwe.rs:55): SystemRng offers exactly the three numpy
+    Generator methods they use, with the right ranges, shapes and moments, and never repeats."""
+    import numpy as np
+    from gpu_common import pkg
+    m = pkg()
+    r = m.SystemRng()
+    bits = r.integers(0, 2, size=(4, 4096))
+    assert bits.shape == (4, 4096) and set(np.unique(bits)) == {0, 1} and abs(bits.mean() - 0.5) < 0.02
+    words = r.integers(0, 1 << 32, size=100000, dtype=np.uint64)
+    assert words.dtype == np.uint64 and int(words.max()) < 1 << 32 and int(words.max()) > 1 << 31
+    assert abs(words.astype(np.float64).mean() / 2.0 ** 32 - 0.5) < 0.01
+    z = r.normal(0.0, 3.0, size=(200000,))
+    assert abs(z.mean()) < 0.05 and abs(z.std() - 3.0) < 0.05
+    assert not np.array_equal(r.integers(0, 1 << 32, size=64, dtype=np.uint64), r.integers(0, 1 << 32, size=64, dtype=np.uint64))
+    import inspect
+    src = inspect.getsource(m.Context.generate_keys) + inspect.getsource(m.Context.encrypt_bits)
+    assert "SystemRng()" in src and "default_rng" not in src

@@ -525,12 +525,13 @@ class Context:
                                                       C.c_size_t(g.shape[0]), _hp(res)))
         return res
 
-    def prepare_ggsw_device(self, ggsw):
+    def prepare_ggsw_device(self, ggsw, out=None):
         """device u32 GGSW(s) -> device NTT-domain GGSW(s) (torch int64 tensor)."""
         import torch
         self._bind_torch()
         count = 1 if ggsw.dim() == 3 else ggsw.shape[0]
-        out = torch.empty((count, self.prepared_ggsw_words()), dtype=torch.int64, device=ggsw.device)
+        if out is None:
+            out = torch.empty((count, self.prepared_ggsw_words()), dtype=torch.int64, device=ggsw.device)
         self._check(lib().tfhe_prepare_ggsw_device(self._h, _dp(ggsw), C.c_size_t(count),
                                                    C.c_void_p(out.data_ptr())))
         return out

@@ -2,6 +2,8 @@
 tools/profile_pmc.sh leaves under gpurun_out/<tag>/ and prints the summary committed under
 profiles/ (plus, with --json, the traffic figure bench.py reports in roofline.traffic).
     python tools/pmc_summarize.py gpurun_out/final/pmc "cfg2 batch 4096" 4096 630 65536 [--json profiles/pmc_traffic.json]
+        [--kernel external_product] [--source profiles/<the file this output is committed as>]
+(for the standalone external-product kernel pass n = 1: one product per sample and launch)
 """
 import csv
 import json
@@ -9,6 +11,13 @@ import sys
 from collections import defaultdict
 
 d, label, batch, n, algo_bytes = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+want = sys.argv[sys.argv.index("--kernel") + 1] if "--kernel" in sys.argv else "blind_rotate"
+source = sys.argv[sys.argv.index("--source") + 1] if "--source" in sys.argv else ""
+# issue floor of the cfg2 kernel's instruction mix at 2 waves per SIMD, from the per-instruction rates of
+# profiles/r02_valu_issue_rates_gfx950.txt (v_fma_f64 5.09, v_mul_f64 4.99, v_add_f64 4.82, v_rndne_f64 4.37,
+# 32-bit integer ops ~4.5) weighted with the shipped kernel's mix (profiles/r02_*_isa_blind_rotate_loops.txt:
+# per wave and iteration 1200 fma, 1140 mul, 1472 add, 584 rndne, 48 cvt, 643 integer)
+FLOOR = (1200 * 5.09 + 1140 * 4.99 + 1472 * 4.82 + 584 * 4.37 + 48 * 5.0 + 643 * 4.5) / 5087
 tot = defaultdict(float)
 launches = defaultdict(set)
 kernel = None
@@ -18,7 +27,7 @@ for name in ("fetch", "write", "sq", "sq2"):
     except FileNotFoundError:
         continue
     for r in rows:
-        if "blind_rotate" not in r["Kernel_Name"]:
+        if want not in r["Kernel_Name"] or "bmmp" in r["Kernel_Name"]:
             continue
         kernel = r["Kernel_Name"].split("(")[0]
         tot[r["Counter_Name"]] += float(r["Counter_Value"])
@@ -49,15 +58,13 @@ if "--json" in sys.argv and "FETCH_SIZE" in per and "WRITE_SIZE" in per:
         cpi = per["GRBM_GUI_ACTIVE"] / 8 * 1024 / per["SQ_INSTS_VALU"]
         valu = {"valu_insts_per_external_product": per["SQ_INSTS_VALU"] / products,
                 "cycles_per_valu_inst_per_simd": cpi,
-                # issue cost of this kernel's mix at 2 waves per SIMD: 84 % fp64 ops at 5.3 cycles,
-                # 16 % integer ops at 4.4 (profiles/r01_dp_chain_latency_gfx950.txt,
-                # profiles/r01_valu_issue_rates_gfx950.txt; the split is DESIGN.md section 4)
-                "issue_floor_cycles_per_inst": 0.84 * 5.3 + 0.16 * 4.4,
-                "valu_issue_frac": min(1.0, (0.84 * 5.3 + 0.16 * 4.4) / cpi),
-                "floor_source": "microbenchmarks under profiles/ (fp64 5.3, integer 4.4 cycles per wave-instruction at 2 waves per SIMD)"}
+                "issue_floor_cycles_per_inst": FLOOR,
+                "valu_issue_frac": min(1.0, FLOOR / cpi),
+                "floor_source": "per-instruction issue rates at 2 waves per SIMD (profiles/r02_valu_issue_rates_gfx950.txt) "
+                                "weighted with the shipped kernel's instruction mix (profiles/r02_*_isa_blind_rotate_loops.txt)"}
     # bench.py matches on "workload" == "<name> batch <batch>": keep it to exactly that
     json.dump({"kernel": "blind_rotate_kernel<fp64-p42,10,1>", "workload": label.split(",")[0], "valu": valu,
                "fetch_size_kib": per["FETCH_SIZE"], "write_size_kib": per["WRITE_SIZE"],
                "traffic_bytes_per_launch": traffic,
                "note": "L2 fabric-side requests (Infinity-Cache hits included); varies with the drift of the teams inside an XCD",
-               "source": "profiles/r01_h_pmc_blind_rotate_cfg2_fp64.txt"}, open(out, "w"), indent=1)
+               "source": source}, open(out, "w"), indent=1)

@@ -9,7 +9,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 run() { # name, counters...
   local name=$1; shift
-  rocprofv3 --pmc "$@" --kernel-include-regex "blind_rotate|external_product" --output-format csv \
+  rocprofv3 --pmc "$@" --kernel-include-regex "${KERNEL_REGEX:-blind_rotate|external_product}" --output-format csv \
       -d "$OUT/$name" -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps 1 --warmup 0 --no-cpu-baseline ${BENCH_ARGS:-} \
       > "$OUT/$name.log" 2>&1 || { echo "pass $name failed"; tail -5 "$OUT/$name.log"; return 1; }
   find "$OUT/$name" -name "*counter_collection.csv" -exec cp {} "$OUT/$name.csv" \;
