@@ -123,11 +123,13 @@ class Engine {
     ctx_.reset(raw);
   }
 
-  // Uploads the key in the reference's own layout (n separate GGSW arrays + the KSK array).
-  void load(const BootstrappingKey& bk) {
+  // Uploads the key in the reference's own layout (n separate GGSW arrays + the KSK array).  A key of
+  // the unrolled blind rotation (notes/BMMP Bootstrapping.md; bootstrapping_key_gen_bmmp below) holds
+  // 3 GGSWs per pair of key bits instead: pass bmmp = true; bootstrap() and the gates then use it.
+  void load(const BootstrappingKey& bk, bool bmmp = false) {
     const size_t ggsw_words = params_.ggsw_rows() * (params_.glwe_dimension + 1) * params_.degree();
-    if (bk.lwe_sk_ggsw_enc.size() != params_.lwe_dimension)
-      throw TfheError(TFHE_ERR_INVALID_ARGUMENT, "bootstrapping key must hold n GGSW ciphertexts");
+    if (bk.lwe_sk_ggsw_enc.size() != (bmmp ? params_.lwe_dimension / 2 * 3 : params_.lwe_dimension))
+      throw TfheError(TFHE_ERR_INVALID_ARGUMENT, "bootstrapping key must hold n (BMMP: 3n/2) GGSW ciphertexts");
     std::vector<uint32_t> flat;
     flat.reserve(ggsw_words * bk.lwe_sk_ggsw_enc.size());
     for (const auto& g : bk.lwe_sk_ggsw_enc) {
@@ -137,8 +139,10 @@ class Engine {
     const size_t ksk_words = params_.lwe_dimension_post_pbs() * params_.ks_decomposer.levels *
                              (size_t(params_.lwe_dimension) + 1);
     if (bk.ksk.data.size() != ksk_words) throw TfheError(TFHE_ERR_INVALID_ARGUMENT, "KSK shape");
-    check(tfhe_load_bootstrapping_key(ctx_.get(), flat.data(), bk.ksk.data.data()));
+    check(bmmp ? tfhe_load_bootstrapping_key_bmmp(ctx_.get(), flat.data(), bk.ksk.data.data())
+               : tfhe_load_bootstrapping_key(ctx_.get(), flat.data(), bk.ksk.data.data()));
   }
+  bool uses_bmmp() const { return tfhe_context_uses_bmmp(ctx_.get()) != 0; }
 
   // Extensions beyond the reference (tfhe_hip.h): the aligned decomposer for bases with
   // beta^l != q, and the key-switch-then-PBS order of notes/TFHE.md:367-400 (ciphertexts of
@@ -442,16 +446,19 @@ KeySwitchingKey generate_ksk(Engine& e, const LweSecretKey& from_lwe_sk, const L
                             to_n, ksk.data.data()));
   return ksk;
 }
-// bootstrapping_key_gen bootstrapping.rs:23-56; the generated key is also installed in the engine
+// bootstrapping_key_gen bootstrapping.rs:23-56; the generated key is also installed in the engine.
+// bmmp = true makes the key of the unrolled blind rotation instead (notes/BMMP Bootstrapping.md:22-24:
+// GGSW(s s'), GGSW(s (1-s')), GGSW(s' (1-s)) per pair of key bits; N = 512, even n).
 template <class Rng>
 BootstrappingKey bootstrapping_key_gen(Engine& e, const LweSecretKey& lwe_secret_key,
-                                       const GlweSecretKey& glwe_secret_key, Rng& rng) {
+                                       const GlweSecretKey& glwe_secret_key, Rng& rng, bool bmmp = false) {
   const TfheParams& p = e.params();
   const size_t n = p.lwe_dimension, row_words = (p.glwe_dimension + 1) * p.degree();
   const size_t ggsw_words = p.ggsw_rows() * row_words;
+  const size_t ggsws = bmmp ? n / 2 * 3 : n;
   if (lwe_secret_key.data.size() != n) throw TfheError(TFHE_ERR_INVALID_ARGUMENT, "lwe secret key shape");
-  std::vector<uint32_t> bsk(n * ggsw_words);
-  for (size_t r = 0; r < n * p.ggsw_rows(); ++r) fill_glwe_samples(p, rng, bsk.data() + r * row_words);
+  std::vector<uint32_t> bsk(ggsws * ggsw_words);
+  for (size_t r = 0; r < ggsws * p.ggsw_rows(); ++r) fill_glwe_samples(p, rng, bsk.data() + r * row_words);
   const size_t ks_rows = p.lwe_dimension_post_pbs() * p.ks_decomposer.levels;
   KeySwitchingKey ksk{std::vector<uint32_t>(ks_rows * (n + 1))};
   for (size_t r = 0; r < ks_rows; ++r) {
@@ -459,11 +466,11 @@ BootstrappingKey bootstrapping_key_gen(Engine& e, const LweSecretKey& lwe_secret
     sample_gaussian_slice(p.lwe_std_dev, rng, row + n, 1);
     sample_uniform_slice(rng, row, n);
   }
-  e.check(tfhe_bootstrapping_key_gen(e.raw(), lwe_secret_key.data.data(), glwe_secret_key.data.data(), bsk.data(),
-                                     ksk.data.data(), 1));
+  e.check((bmmp ? tfhe_bootstrapping_key_gen_bmmp : tfhe_bootstrapping_key_gen)(
+      e.raw(), lwe_secret_key.data.data(), glwe_secret_key.data.data(), bsk.data(), ksk.data.data(), 1));
   BootstrappingKey bk;
-  bk.lwe_sk_ggsw_enc.reserve(n);
-  for (size_t i = 0; i < n; ++i)
+  bk.lwe_sk_ggsw_enc.reserve(ggsws);
+  for (size_t i = 0; i < ggsws; ++i)
     bk.lwe_sk_ggsw_enc.push_back(
         GgswCiphertext{std::vector<uint32_t>(bsk.begin() + i * ggsw_words, bsk.begin() + (i + 1) * ggsw_words)});
   bk.ksk = std::move(ksk);

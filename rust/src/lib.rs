@@ -32,6 +32,7 @@ extern "C" {
     fn tfhe_context_destroy(ctx: *mut TfheContext);
     fn tfhe_last_error(ctx: *const TfheContext) -> *const c_char;
     fn tfhe_load_bootstrapping_key(ctx: *mut TfheContext, bsk: *const u32, ksk: *const u32) -> c_int;
+    fn tfhe_load_bootstrapping_key_bmmp(ctx: *mut TfheContext, bsk_bmmp: *const u32, ksk: *const u32) -> c_int;
     fn tfhe_bootstrap_batch(ctx: *mut TfheContext, lwe_in: *const u32, batch: usize,
                             test_vector_poly: *const u32, tv_count: usize, lwe_out: *mut u32) -> c_int;
     fn tfhe_key_switch_batch(ctx: *mut TfheContext, lwe_in: *const u32, batch: usize, lwe_out: *mut u32) -> c_int;
@@ -83,6 +84,17 @@ impl GpuBootstrappingKey {
         let st = unsafe { tfhe_context_create(params, 0, &mut ctx) };
         assert!(st == 0, "tfhe_context_create: status {st}");
         check(ctx, unsafe { tfhe_load_bootstrapping_key(ctx, bsk.as_ptr(), ksk.as_ptr()) }, "load key");
+        GpuBootstrappingKey { ctx, params: *params }
+    }
+
+    /// Key of the unrolled blind rotation the crate sketches in notes/BMMP Bootstrapping.md:13-25:
+    /// `bsk_bmmp` [n/2][3][(k+1)l][k+1][N] = GGSW(s s'), GGSW(s (1-s')), GGSW(s' (1-s)) per pair of key
+    /// bits.  `bootstrap` / the gates then consume two key bits per step (N = 512, even n).
+    pub fn upload_bmmp_flat(params: &CTfheParams, bsk_bmmp: &[u32], ksk: &[u32]) -> Self {
+        let mut ctx = std::ptr::null_mut();
+        let st = unsafe { tfhe_context_create(params, 0, &mut ctx) };
+        assert!(st == 0, "tfhe_context_create: status {st}");
+        check(ctx, unsafe { tfhe_load_bootstrapping_key_bmmp(ctx, bsk_bmmp.as_ptr(), ksk.as_ptr()) }, "load BMMP key");
         GpuBootstrappingKey { ctx, params: *params }
     }
 }

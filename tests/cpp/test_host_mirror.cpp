@@ -192,6 +192,21 @@ int main() {
       encrypt_lwe_plaintext(e2, 1e-5, bad, 0u, gen);
     } catch (const TfheError&) { threw = true; }
     EXPECT(threw, "non-binary secret key refused");
+    // the unrolled blind rotation of notes/BMMP Bootstrapping.md through the mirror: a BMMP key made on
+    // the GPU (3 GGSWs per pair of key bits), bootstrapping_works on top of it, then back to the loop
+    if (N == 512 && n % 2 == 0) {
+      BootstrappingKey bmmp = bootstrapping_key_gen(e2, lwe_secret_key, glwe_secret_key, gen, /*bmmp=*/true);
+      EXPECT(bmmp.lwe_sk_ggsw_enc.size() == n / 2 * 3 && e2.uses_bmmp(), "BMMP key shape / mode");
+      for (uint32_t m = 0; m < 4; ++m) {
+        LweCiphertext ct = encrypt_lwe_plaintext(e2, tfhe_params.lwe_std_dev, lwe_secret_key,
+                                                 encode_message(m, tfhe_params), gen);
+        EXPECT(dec_msg(bootstrap(e2, ct, test_vector_poly)) == m, "bootstrapping_works with a BMMP key");
+      }
+      e2.load(bk);
+      EXPECT(!e2.uses_bmmp(), "an ordinary key switches back to the reference's loop");
+      e2.load(bmmp, true);
+      EXPECT(e2.uses_bmmp(), "BMMP key reloaded");
+    }
   }
   // error behaviour: the reference panics, the mirror throws
   {

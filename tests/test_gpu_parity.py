@@ -277,6 +277,34 @@ def test_backend_selection(oracle):
     assert e.value.status == 7
 
 
+@pytest.mark.parametrize("log_base", [24, 27, 31])
+def test_one_level_decompositions_with_bases_above_two_to_the_23(oracle, log_base):
+    """decomposer.rs:42-80 accepts any log_base < 32 with log_base * levels <= 32: one level of 24, 27 or 31
+    bits (digits up to 2^31).  The kernels' digit chain uses a 24-bit multiply-add only below 2^23 and plain
+    shifts above; these shapes land in the split-key Goldilocks field.  Rows with every limb pattern that
+    matters: all ones (digit = B after the carry), the half bit alone, random words."""
+    m = pkg()
+    p = oracle.Params(1, 9, 3, oracle.Decomposer(log_base, 1))
+    lwe, bsk, ksk, tv = oracle.synthetic_inputs(p, 6, cfg_index=100 + log_base)
+    rng = np.random.default_rng(log_base)
+    ggsw = rng.integers(0, 1 << 32, size=(p.R, 2, p.N), dtype=np.uint64).astype(np.uint32)
+    glwe = rng.integers(0, 1 << 32, size=(4, 2, p.N), dtype=np.uint64).astype(np.uint32)
+    glwe[0, :, :] = 0xFFFFFFFF
+    glwe[1, :, ::2] = np.uint32(1) << np.uint32(31)
+    glwe[1, :, 1::2] = (np.uint32(1) << np.uint32(32 - log_base + log_base - 1)) - np.uint32(1)
+    with m.Context(to_pkg_params(p)) as ctx:
+        assert ctx.backend == "goldilocks-split"
+        ctx.load_bootstrapping_key(bsk, ksk)
+        out = ctx.bootstrap(lwe, tv)
+        got = ctx.external_product(ggsw, glwe)
+        digits = ctx.decompose(glwe[:2].reshape(-1)[:4096])
+    for b in range(lwe.shape[0]):
+        assert np.array_equal(out[b], oracle.bootstrap(p, lwe[b], bsk, ksk, tv)), (log_base, b)
+    for b in range(4):
+        assert np.array_equal(got[b], oracle.external_product(p, ggsw, glwe[b])), (log_base, b)
+    assert np.array_equal(digits, oracle.decompose(p.pbs, glwe[:2].reshape(-1)[:4096]))
+
+
 def test_full_size_cfg3_nand_gate_stream(oracle):
     """BASELINE cfg3 = the reference's default parameters (lib.rs:101-123: N=512, k=2, n=722, l=6,
     logB=4) with REAL keys: a stream of NAND gates through the closure hook (test_vector.rs:5),

@@ -63,6 +63,7 @@ struct FpField {
   // reduction needed.  The unreduced value (up to 2^52) only ever gets ADDED to later-stage terms
   // (<= +p/2 per stage) or passes through mul(), which accepts any |a| < 2^53.
   static constexpr int kSmallBits = 9;
+  static constexpr int kMaxLogBase = kSmallBits;  // the context refuses larger bases for this field
   TFHE_HD static elem mul_small(elem a, elem w) { return a * w; }
   // The first two Cooley-Tukey stages on four small inputs |a|,|b|,|c|,|d| <= 2^9 as one exact
   // radix-4 step: every product is below 2^50 and every output is a sum of at most three products

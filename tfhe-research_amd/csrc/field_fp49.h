@@ -76,6 +76,8 @@ struct Fp49Field {
   }
   // no reduction-free small stage here: 2^4 * p/2 already touches 2^53
   static constexpr int kSmallBits = 31;
+  // (k+1) l N B 2^31 < 2^48.25 with N >= 512 and (k+1) l >= 2 leaves B < 2^7.25
+  static constexpr int kMaxLogBase = 8;
   TFHE_HD static elem mul_small(elem a, elem w) { return mul(a, w); }
   static constexpr bool kFuseFirstTwo = false;
   TFHE_HD static void radix4_small(elem&, elem&, elem&, elem&, elem, elem, elem, elem, elem) {}

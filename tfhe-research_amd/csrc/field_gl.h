@@ -29,6 +29,7 @@ struct GlFieldT {
   TFHE_HD static elem sub(elem a, elem b) { return gl::sub(a, b); }
   TFHE_HD static elem mul(elem a, elem w) { return gl::mul(a, w); }
   static constexpr int kSmallBits = 31;  // mul_small is the full product here: any digit qualifies
+  static constexpr int kMaxLogBase = 31;
   TFHE_HD static elem mul_small(elem a, elem w) { return gl::mul(a, w); }
   static constexpr bool kFuseFirstTwo = false;  // canonical u64 arithmetic gains nothing from it
   TFHE_HD static void radix4_small(elem&, elem&, elem&, elem&, elem, elem, elem, elem, elem) {}

@@ -76,14 +76,21 @@ TFHE_HD u32 decompose_limb(u32 v, u32 shift, u32 log_base, u32& carry) {
 // extract, the carry-in another (width `carry_width`: 0 for the lowest limb, 1 after), the carry-out
 // is written back by one bit-field insert of res's bit log_base-1, digit = res - 2 * (res & B/2) is
 // one multiply-add.
+// SMALL_BASE: log_base <= 23, so that res & B/2 fits the signed 24-bit multiply-add (wave-uniform; the
+// caller branches once per level).
+template <bool SMALL_BASE>
 TFHE_HD u32 decompose_limb_fast(u32& v, u32 shift, u32 log_base, u32 carry_width) {
   const u32 half = 1u << (log_base - 1);
 #if defined(__HIP_DEVICE_COMPILE__)
   const u32 res = __builtin_amdgcn_ubfe(v, shift, log_base) + __builtin_amdgcn_ubfe(v, log_base - 1, carry_width);
   const u32 hb = res & half;
   u32 digit;
-  // (res, hb < 2^17: the signed 24-bit multiply-add is exact) digit = hb * -2 + res
-  asm("v_mad_i32_i24 %0, %1, -2, %2" : "=v"(digit) : "v"(hb), "v"(res));
+  if (SMALL_BASE) {
+    // hb < 2^23: the signed 24-bit multiply-add is exact (its addend is a full 32-bit word)
+    asm("v_mad_i32_i24 %0, %1, -2, %2" : "=v"(digit) : "v"(hb), "v"(res));
+  } else {
+    digit = res - (hb << 1);
+  }
   asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(v) : "s"(half), "v"(res), "v"(v));  // v = (res & half) | (v & ~half)
   return digit;
 #else
@@ -212,8 +219,15 @@ TFHE_HD void external_product_team_keys(const Ctx& c, const PbsParams& P, const 
     {
       elem work[E];
       const u32 carry_width = (t == 0) ? 0u : 1u;  // wave-uniform: the lowest kept limb has no carry-in
+      // F::kMaxLogBase: the largest gadget base the field's exactness bound admits at all; only the
+      // Goldilocks fields reach bases above 2^23 (one-level decompositions) and branch at run time
+      if (F::kMaxLogBase <= 23 || P.log_base <= 23) {
 #pragma unroll
-      for (int r = 0; r < E; ++r) work[r] = F::from_digit(decompose_limb_fast(v[r], shift, P.log_base, carry_width));
+        for (int r = 0; r < E; ++r) work[r] = F::from_digit(decompose_limb_fast<true>(v[r], shift, P.log_base, carry_width));
+      } else {
+#pragma unroll
+        for (int r = 0; r < E; ++r) work[r] = F::from_digit(decompose_limb_fast<false>(v[r], shift, P.log_base, carry_width));
+      }
       // digits are tiny (|d| <= B <= 2^F::kSmallBits, enforced when the context picks the field):
       // the first butterfly stage uses F::mul_small.  A team barrier precedes every level (the
       // caller's for level 0, the previous level's below) and nobody reads this buffer after it.
