@@ -68,8 +68,13 @@ struct DeviceWave {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
   // workgroup barrier: the team of K+1 groups that shares one sample IS the workgroup
-  // (timing experiment: compiling the barriers out changes cfg2 by -1 % and makes cfg3 20 % SLOWER --
-  // they cost next to nothing and keep the team's key accesses together)
+  // (timing experiments with the barriers compiled out: cfg2 -1 %, cfg3 20 % SLOWER -- there they cost
+  // next to nothing and keep the team's key accesses together; cfg5, one 12-wave team per CU and 13
+  // workgroup barriers per product: 78.6 -> 67.2 ms, i.e. 14.5 % of that kernel is barrier wait.  A
+  // barrier scoped to the 4 waves of one polynomial group (LDS arrival counter + bounded spin) for the
+  // 8 barriers that only order a group's cross-wave transposes was built and measured: bit-exact, same
+  // time (78.88 vs 78.95 ms) -- the wait is the drift between waves that share SIMDs three at a time,
+  // whatever the scope.  profiles/r02_kernel_ab.txt)
   __device__ __forceinline__ void team_sync() const { __syncthreads(); }
   __device__ __forceinline__ Elem* scratch() const { return scratch_; }
   __device__ __forceinline__ const Elem* scratch_of(int s) const {
