@@ -377,30 +377,47 @@ def test_batch_4096_properties_cfg2(oracle):
         assert np.array_equal(base[b], oracle.bootstrap(p, lwe[b], bsk, ksk, tv)), b
 
 
-@pytest.mark.parametrize("per_sample", [False, True], ids=["shared-ggsw", "ggsw-per-sample"])
-def test_external_product_batches_beyond_the_resident_teams(oracle, per_sample):
+@pytest.mark.parametrize("batch,per_sample", [(5000, False), (5000, True), (20000, False), (17000, True)],
+                         ids=["stride-shared-ggsw", "stride-ggsw-per-sample", "queue-shared-ggsw", "queue-ggsw-per-sample"])
+def test_external_product_batches_beyond_the_resident_teams(oracle, batch, per_sample):
     """The standalone external-product kernel is a persistent grid: with more samples than resident teams
-    (1,024 at this shape) every team walks several samples.  5,000 products (not a multiple of the
-    grid) through the device entry point against the same products launched in chunks of 256 (one sample per
-    team) and against the oracle on rows of the first, a middle and the last pass."""
+    (1,024 at this shape) every team walks several samples -- by stride up to 15 per team, through a
+    device work queue from 16.  Batches that are not multiples of the grid, through the device entry point,
+    against the same products launched in chunks of 256 (one sample per team) and against the oracle on rows
+    of the first, a middle and the last pass; the queue's counters must be back at zero after every launch
+    (three launches in a row, then three replays of a captured graph)."""
     import torch
     p = oracle.Params(1, 10, 4, oracle.Decomposer(7, 3))
     m = pkg()
     dev = torch.device("cuda", 0)
     gen = torch.Generator(device=dev).manual_seed(77)
     rw = lambda *s: torch.randint(-(1 << 31), (1 << 31) - 1, s, dtype=torch.int32, device=dev, generator=gen)
-    batch = 5000
     with m.Context(to_pkg_params(p)) as ctx:
         ggsw = rw(batch if per_sample else 1, p.R, p.k + 1, p.N)
         prep = ctx.prepare_ggsw_device(ggsw)
         glwe = rw(batch, p.k + 1, p.N)
         full = ctx.external_product_prepared(prep, glwe)
-        parts = [ctx.external_product_prepared(prep[i:i + 256] if per_sample else prep, glwe[i:i + 256].contiguous())
-                 for i in range(0, batch, 256)]
-        assert torch.equal(full, torch.cat(parts))
+        parts = torch.cat([ctx.external_product_prepared(prep[i:i + 256] if per_sample else prep, glwe[i:i + 256].contiguous())
+                           for i in range(0, batch, 256)])
+        assert torch.equal(full, parts)
+        for _ in range(2):
+            assert torch.equal(ctx.external_product_prepared(prep, glwe), parts)
+        side = torch.cuda.Stream()
+        out = torch.empty_like(glwe)
+        with torch.cuda.stream(side):
+            ctx.external_product_prepared(prep, glwe, out=out)
+            side.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                ctx.external_product_prepared(prep, glwe, out=out)
+            for _ in range(3):
+                out.zero_()
+                graph.replay()
+                side.synchronize()
+                assert torch.equal(out, parts)
         gg, gl, fu = (t.cpu().numpy().view(np.uint32) for t in (ggsw, glwe, full))
         ctx.set_stream(None)
-    for b in (0, 1023, 1024, 2500, 4095, 4999):
+    for b in (0, 1023, 1024, batch // 2, batch - 2, batch - 1):
         assert np.array_equal(fu[b], oracle.external_product(p, gg[b if per_sample else 0], gl[b])), b
 
 

@@ -33,6 +33,7 @@ struct tfhe_context {
   int field = 0;              // launch::kFieldGoldilocks | launch::kFieldFp64
   int parts = 1;              // spectra per key polynomial in this field
   void* d_tw = nullptr;       // psi_rev[N], 8-byte field elements
+  unsigned long long* d_queue = nullptr;  // work-queue counters of the external-product kernel (zero between launches)
   void* d_bsk = nullptr;      // prepared BSK [n][R][k+1][parts][N] (spectrum_slot order, x 1/N)
   u32* d_ksk = nullptr;       // [big_n*l_ks][n+1]
   bool have_key = false;
@@ -398,6 +399,9 @@ int tfhe_context_create_with_backend(const tfhe_params* params, int device, int 
       : field == launch::kFieldFp49 ? upload_twiddles<Fp49Field>(ctx)
                                     : upload_twiddles<GlField>(ctx);  // both Goldilocks fields share the table
   if (e != hipSuccess) return bail(e, "twiddle upload");
+  if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->d_queue), 2 * sizeof(unsigned long long))) != hipSuccess ||
+      (e = hipMemset(ctx->d_queue, 0, 2 * sizeof(unsigned long long))) != hipSuccess)
+    return bail(e, "work queue");
   *out = ctx;
   return TFHE_OK;
 }
@@ -424,7 +428,7 @@ void tfhe_context_destroy(tfhe_context* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  void* ptrs[] = {ctx->d_tw,     ctx->d_bsk,    ctx->d_ksk,    ctx->d_lwe_in, ctx->d_lwe_in2,
+  void* ptrs[] = {ctx->d_queue,  ctx->d_tw,     ctx->d_bsk,    ctx->d_ksk,    ctx->d_lwe_in, ctx->d_lwe_in2,
                   ctx->d_lwe_big, ctx->d_lwe_out, ctx->d_lwe_ks, ctx->d_glwe_a, ctx->d_glwe_b, ctx->d_glwe_c,
                   ctx->d_tv,     ctx->d_misc,   ctx->d_ggsw_tmp, ctx->d_ggsw_raw,
                   ctx->d_key_tmp};
@@ -770,7 +774,7 @@ int tfhe_external_product_prepared_device(tfhe_context* ctx, const void* ggsw_pr
   if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
   HIP_TRY(ctx, launch::external_product(ctx->stream, ctx->field, ctx->pbs, ctx->d_tw, ggsw_prepared,
                                         ggsw_count == 1 ? 0 : ggsw_words(ctx) * ctx->parts, glwe_in,
-                                        nullptr, nullptr, batch, glwe_out));
+                                        nullptr, nullptr, batch, glwe_out, ctx->d_queue));
   if (ctx->timing) {
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     ctx->ev_valid_br = true;
@@ -819,7 +823,7 @@ int tfhe_cmux_batch(tfhe_context* ctx, const uint32_t* ggsw, size_t ggsw_count, 
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_glwe_b, ct1, batch * glwe * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, launch::external_product(ctx->stream, ctx->field, ctx->pbs, ctx->d_tw, ctx->d_ggsw_tmp,
                                         ggsw_count == 1 ? 0 : ggsw_words(ctx) * ctx->parts, nullptr,
-                                        ctx->d_glwe_b, ctx->d_glwe_a, batch, ctx->d_glwe_c));
+                                        ctx->d_glwe_b, ctx->d_glwe_a, batch, ctx->d_glwe_c, ctx->d_queue));
   HIP_TRY(ctx, hipMemcpyAsync(glwe_out, ctx->d_glwe_c, batch * glwe * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(ct1, ctx->d_glwe_b, batch * glwe * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -238,16 +238,22 @@ blind_rotate_bmmp_kernel(PbsParams P, const typename F::elem* __restrict__ tw,
 }
 
 // ------------------------------------------------------------------------------ external product
-// Persistent grid: a team takes samples blockIdx.x, blockIdx.x + gridDim.x, ... so the twiddle
-// table is staged into LDS once per team instead of once per sample (the launcher sizes the grid to
-// the teams that are resident at once).  Both forms of the reference call go through ONE
+// Persistent grid: the launcher starts as many teams as are resident at once, so the twiddle table is
+// staged into LDS once per team.  Short batches are handed out by stride (blockIdx.x, + gridDim.x, ...),
+// long ones through a work queue.  Why both: a grid that exactly fills the chip with a FIXED share per
+// team ends when its slowest CU does -- the same team code ran 7-12 % slower per product that way than
+// under the dispatcher's dynamic placement of a larger grid -- so at 64 samples per team drawing tickets
+// from a device counter is 5.7 % faster; with a handful of samples per team a queue only makes some
+// teams take one more than the others (4 per team: +15 %, and +5 % even when only the tail is queued),
+// so the launcher uses it from 16 samples per team (profiles/r02_external_product_experiments.txt).
+// queue[0] hands out tickets, queue[1] counts the teams that have drained it; the last one resets both, so a launch leaves
+// the counters at zero -- no host state, safe to capture into a graph and replay.  Both forms of the reference call go through ONE
 // instantiation of the team code: the plain product (ggsw.rs:132-161) and the CMUX form
-// (ggsw.rs:164-178: ct1 -= ct0 is written back, the product is added to ct0); `cmux_ct0` is a
-// kernel argument, so the selects below are wave-uniform branches.  (Measured and dropped,
-// profiles/r02_external_product_experiments.txt: fetching the next sample's operand early -- by
-// LDS-DMA or into registers behind the inverse transforms --, starting the teams out of phase and
-// oversubscribing the grid all left the time per product unchanged within 2 %; with loads and
-// stores compiled out the kernel is only 4 % faster: it is the team code itself that bounds it.)
+// (ggsw.rs:164-178: ct1 -= ct0 is written back, the product is added to ct0); `cmux_ct0` is a kernel
+// argument, so the selects below are wave-uniform branches.  (Measured and dropped: fetching the next
+// sample's operand early -- by LDS-DMA or into registers behind the inverse transforms -- and starting
+// the teams out of phase left the time per product unchanged within 2 %; with loads and stores compiled
+// out the kernel is only 4 % faster.)
 template <class F, int LOGN, int K>
 __global__ void __launch_bounds__((TeamCfg<LOGN, K>::kThreads),
                                   (F::kId == FpField::kId || F::kId == Fp49Field::kId
@@ -256,14 +262,24 @@ __global__ void __launch_bounds__((TeamCfg<LOGN, K>::kThreads),
 external_product_kernel(PbsParams P, const typename F::elem* __restrict__ tw,
                         const typename F::elem* __restrict__ ggsw, size_t ggsw_stride_words,
                         const u32* glwe_in, u32* ct1_inout, const u32* cmux_ct0, size_t batch,
-                        u32* glwe_out) {
+                        u32* glwe_out, unsigned long long* queue /* null: by stride */) {
   using C = TeamCfg<LOGN, K>;
   constexpr int N = C::N;
   constexpr int G = C::G;
   auto w = make_wave<F, LOGN, K>(g_smem, tw);
   const bool is_cmux = cmux_ct0 != nullptr;
-  // every wave of the team walks the same samples: the barriers inside the team code stay matched
-  for (size_t sample = blockIdx.x; sample < batch; sample += gridDim.x) {
+  // the ticket of the team's current sample, published through LDS (behind the team's arrays)
+  unsigned long long* ticket = reinterpret_cast<unsigned long long*>(g_smem + C::kLds);
+  for (size_t turn = 0;; ++turn) {
+    size_t sample;
+    if (queue == nullptr) {
+      sample = blockIdx.x + turn * gridDim.x;
+    } else {
+      if (threadIdx.x == 0) *ticket = atomicAdd(queue, 1ull);
+      __syncthreads();  // every wave of the team sees the same ticket: the barriers below stay matched
+      sample = (size_t)*ticket;
+    }
+    if (sample >= batch) break;
     const size_t poly = (sample * (size_t)(K + 1) + w.group()) * N;  // my polynomial / my output column
     const typename F::elem* g = ggsw + sample * ggsw_stride_words;
     const u32* in = is_cmux ? ct1_inout + poly : glwe_in + poly;
@@ -282,6 +298,12 @@ external_product_kernel(PbsParams P, const typename F::elem* __restrict__ tw,
     };
     auto out = [&](int j, u32 v) { __builtin_nontemporal_store(is_cmux ? v + c0[j] : v, &dst[j]); };
     external_product_team<F, LOGN, K, G>(w, P, g, src, out);
+    // (thread 0 overwrites the ticket only after the product's team barriers, which every wave passes
+    // after it has read the ticket)
+  }
+  if (queue != nullptr && threadIdx.x == 0 && atomicAdd(queue + 1, 1ull) == (unsigned long long)gridDim.x - 1ull) {
+    atomicExch(queue, 0ull);  // every team has made its last draw: leave the counters ready for the next launch
+    atomicExch(queue + 1, 0ull);
   }
 }
 
@@ -643,13 +665,15 @@ hipError_t launch_blind_rotate_bmmp(hipStream_t s, const PbsParams& P, const voi
 template <class F, int LOGN, int K>
 hipError_t launch_external_product(hipStream_t s, const PbsParams& P, const void* tw_v,
                                    const void* ggsw_v, size_t ggsw_stride_words, const u32* glwe_in,
-                                   u32* ct1_inout, const u32* cmux_ct0, size_t batch, u32* glwe_out) {
+                                   u32* ct1_inout, const u32* cmux_ct0, size_t batch, u32* glwe_out,
+                                   unsigned long long* queue) {
   using C = TeamCfg<LOGN, K>;
+  constexpr size_t kLdsWithTicket = C::kLds + 16;
   auto tw = static_cast<const typename F::elem*>(tw_v);
   auto ggsw = static_cast<const typename F::elem*>(ggsw_v);
   auto kern = external_product_kernel<F, LOGN, K>;
   static std::atomic<unsigned long long> lds_done{0};
-  hipError_t e = allow_lds(kern, C::kLds, lds_done);
+  hipError_t e = allow_lds(kern, kLdsWithTicket, lds_done);
   if (e != hipSuccess) return e;
   // persistent grid: as many teams as the device keeps resident at once (LDS or registers decide)
   static std::atomic<int> resident{0};
@@ -659,14 +683,16 @@ hipError_t launch_external_product(hipStream_t s, const PbsParams& P, const void
     e = hipGetDevice(&dev);
     if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (e == hipSuccess)
-      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), C::kThreads, C::kLds);
+      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), C::kThreads, kLdsWithTicket);
     if (e != hipSuccess) return e;
     teams = cus * (per_cu > 0 ? per_cu : 1);
     resident.store(teams, std::memory_order_relaxed);
   }
   const size_t grid = batch < (size_t)teams ? batch : (size_t)teams;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C::kThreads), C::kLds, s, P, tw, ggsw,
-                     ggsw_stride_words, glwe_in, ct1_inout, cmux_ct0, batch, glwe_out);
+  // the work queue pays from 16 samples per team (see the kernel)
+  unsigned long long* use_queue = batch / grid >= 16 ? queue : nullptr;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C::kThreads), kLdsWithTicket, s, P, tw, ggsw,
+                     ggsw_stride_words, glwe_in, ct1_inout, cmux_ct0, batch, glwe_out, use_queue);
   return hipGetLastError();
 }
 
@@ -823,10 +849,11 @@ hipError_t blind_rotate_bmmp(hipStream_t s, int field, const PbsParams& P, const
 
 hipError_t external_product(hipStream_t s, int field, const PbsParams& P, const void* tw,
                             const void* ggsw, size_t ggsw_stride_words, const u32* glwe_in,
-                            u32* ct1_inout, const u32* cmux_ct0, size_t batch, u32* glwe_out) {
+                            u32* ct1_inout, const u32* cmux_ct0, size_t batch, u32* glwe_out,
+                            unsigned long long* queue) {
   TFHE_DISPATCH_FIELD(field, TFHE_DISPATCH_LOGN_K(P.log_n, P.k,
                       (launch_external_product<FF, LL, KK>(s, P, tw, ggsw, ggsw_stride_words, glwe_in,
-                                                           ct1_inout, cmux_ct0, batch, glwe_out))));
+                                                           ct1_inout, cmux_ct0, batch, glwe_out, queue))));
 }
 
 hipError_t key_switch(hipStream_t s, const KsParams& K, u32 big_n, u32 n, const u32* lwe_in,
