@@ -33,7 +33,7 @@ struct tfhe_context {
   int field = 0;              // launch::kFieldGoldilocks | launch::kFieldFp64
   int parts = 1;              // spectra per key polynomial in this field
   void* d_tw = nullptr;       // psi_rev[N], 8-byte field elements
-  unsigned long long* d_queue = nullptr;  // work-queue counters of the external-product kernel (zero between launches)
+  unsigned long long* d_queue = nullptr;  // ticket counter of the external-product kernel's work queue
   void* d_bsk = nullptr;      // prepared BSK [n][R][k+1][parts][N] (spectrum_slot order, x 1/N)
   u32* d_ksk = nullptr;       // [big_n*l_ks][n+1]
   bool have_key = false;

@@ -246,8 +246,8 @@ blind_rotate_bmmp_kernel(PbsParams P, const typename F::elem* __restrict__ tw,
 // from a device counter is 5.7 % faster; with a handful of samples per team a queue only makes some
 // teams take one more than the others (4 per team: +15 %, and +5 % even when only the tail is queued),
 // so the launcher uses it from 16 samples per team (profiles/r02_external_product_experiments.txt).
-// queue[0] hands out tickets, queue[1] counts the teams that have drained it; the last one resets both, so a launch leaves
-// the counters at zero -- no host state, safe to capture into a graph and replay.  Both forms of the reference call go through ONE
+// queue[0] hands out tickets; the launcher zeroes it on the stream right before the kernel (a memset node
+// when the call is captured into a graph, so replays start from zero too).  Both forms of the reference call go through ONE
 // instantiation of the team code: the plain product (ggsw.rs:132-161) and the CMUX form
 // (ggsw.rs:164-178: ct1 -= ct0 is written back, the product is added to ct0); `cmux_ct0` is a kernel
 // argument, so the selects below are wave-uniform branches.  (Measured and dropped: fetching the next
@@ -300,10 +300,6 @@ external_product_kernel(PbsParams P, const typename F::elem* __restrict__ tw,
     external_product_team<F, LOGN, K, G>(w, P, g, src, out);
     // (thread 0 overwrites the ticket only after the product's team barriers, which every wave passes
     // after it has read the ticket)
-  }
-  if (queue != nullptr && threadIdx.x == 0 && atomicAdd(queue + 1, 1ull) == (unsigned long long)gridDim.x - 1ull) {
-    atomicExch(queue, 0ull);  // every team has made its last draw: leave the counters ready for the next launch
-    atomicExch(queue + 1, 0ull);
   }
 }
 
@@ -691,6 +687,7 @@ hipError_t launch_external_product(hipStream_t s, const PbsParams& P, const void
   const size_t grid = batch < (size_t)teams ? batch : (size_t)teams;
   // the work queue pays from 16 samples per team (see the kernel)
   unsigned long long* use_queue = batch / grid >= 16 ? queue : nullptr;
+  if (use_queue && (e = hipMemsetAsync(use_queue, 0, sizeof(unsigned long long), s)) != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C::kThreads), kLdsWithTicket, s, P, tw, ggsw,
                      ggsw_stride_words, glwe_in, ct1_inout, cmux_ct0, batch, glwe_out, use_queue);
   return hipGetLastError();

@@ -43,7 +43,7 @@ hipError_t blind_rotate_bmmp(hipStream_t s, int field, const PbsParams& P, const
 hipError_t external_product(hipStream_t s, int field, const PbsParams& P, const void* tw,
                             const void* ggsw, size_t ggsw_stride_words, const u32* glwe_in,
                             u32* ct1_inout, const u32* cmux_ct0, size_t batch, u32* glwe_out,
-                            unsigned long long* queue /* 2 device words, zero between launches */);
+                            unsigned long long* queue /* one device word of scratch: ticket counter of long batches */);
 
 // key_switch_lwe over a batch: lwe_in [batch][big_n+1], ksk [big_n*levels][n+1], out [batch][n+1]
 hipError_t key_switch(hipStream_t s, const KsParams& K, u32 big_n, u32 n, const u32* lwe_in,
