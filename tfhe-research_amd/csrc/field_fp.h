@@ -36,7 +36,8 @@ struct FpField {
   // (h, l) accumulator pairs (field_fp49.h) are not used here: summing unreduced products would cut the
   // multiply-accumulate from 7 to 4 instructions per term, but the second accumulator set does not fit
   // the register budget of any shape -- measured with the 4-instruction form (accumulate inside the
-  // binade of 1.5 * 2^100): 83 spilled registers at N = 1024 (256-register budget), 37-80 at N = 512 /
+  // binade of 1.5 * 2^100): 83-85 spilled registers at N = 1024 (256-register budget; before and after the
+  // scalar-twiddle change), 37-80 at N = 512 /
   // N = 2048 over four waves (168-register budget for three waves per SIMD), profiles/r02_*.
   template <int E>
   static constexpr bool split_accum() { return false; }
