@@ -306,34 +306,52 @@ external_product_kernel(PbsParams P, const typename F::elem* __restrict__ tw,
 // ------------------------------------------------------------------------------ key switch
 // out[b][c] = -sum_{i<big_n, l<levels} digit_l(lwe[b][i]) * ksk[i*levels + l][c];  out[b][n] += b
 // Tiled as a wrapping-u32 GEMM: a workgroup owns kKsSamples samples x 128 output columns and walks
-// key rows in chunks; digits of the chunk are produced once into LDS.  Small batches do not give
-// enough (sample, column) tiles to fill 256 CUs, so the big_n mask words are also split over
-// gridDim.z: with more than one split the partial sums go to the (pre-zeroed) output with u32
-// atomic adds -- wrapping addition is associative and commutative, the bits do not depend on the
-// order.
+// key rows in chunks; digits of the chunk are produced once into LDS.  The key rows are staged through
+// LDS as well, kKsKeyRows at a time and double-buffered: the four waves of a workgroup all need the same
+// 128 columns of every row (they differ in the samples they own), and reading them straight from global
+// memory quadrupled the L1 traffic -- 512 B per wave and row at ~75 cycles per row and ten waves per CU is
+// more than the 64 B/clk a CU's vector L1 delivers, which is what bounded the kernel (1.30 ms against a
+// 0.39 ms multiply-add floor at cfg2).  Small batches do not give enough (sample, column) tiles to fill
+// 256 CUs, so the big_n mask words are also split over gridDim.z: with more than one split the partial
+// sums go to the (pre-zeroed) output with u32 atomic adds -- wrapping addition is associative and
+// commutative, the bits do not depend on the order.
 constexpr int kKsSamples = 32;     // samples per workgroup
 constexpr int kKsColsPerLane = 2;  // output columns per lane
 constexpr int kKsCols = 64 * kKsColsPerLane;  // output columns per workgroup
 constexpr int kKsWords = 8;        // mask words decomposed per chunk
 constexpr int kKsPerThread = 8;    // samples per thread (kKsSamples / 4 waves)
+constexpr int kKsKeyRows = 16;     // key rows staged in LDS per step (x 128 columns x 4 B = 8 KiB, two buffers)
+constexpr int kKsLoads = kKsKeyRows * kKsCols / 256;  // key words each thread moves per step
+// workgroups a launch should reach before the mask words stop being split over gridDim.z: 16 per CU
+// (cfg2, batch 4096: 640 tiles -> 0.90 ms unsplit, 0.70 ms at 3 splits, 0.59 ms at 6; flat beyond)
+#ifndef TFHE_KS_TARGET_WGS
+#define TFHE_KS_TARGET_WGS 4096u
+#endif
 
 __global__ void __launch_bounds__(256) key_switch_kernel(KsParams Kp, u32 big_n, u32 n,
                                                          const u32* __restrict__ lwe_in, size_t batch,
                                                          const u32* __restrict__ ksk,
                                                          u32* __restrict__ lwe_out, u32 words_per_split) {
-  u32* dig = reinterpret_cast<u32*>(g_smem);  // [kKsWords*levels][kKsSamples]
+  const u32 levels = Kp.levels;
+  u32* dig = reinterpret_cast<u32*>(g_smem);                 // [kKsWords*levels][kKsSamples]
+  u32* ktile = dig + (size_t)kKsWords * levels * kKsSamples;  // [2][kKsKeyRows][kKsCols]
   const int tx = (int)(threadIdx.x & 63u);
   const int ty = (int)(threadIdx.x >> 6);
   const size_t s0 = (size_t)blockIdx.y * kKsSamples;
   const u32 width = n + 1;
-  const u32 levels = Kp.levels;
+  const u32 col0 = blockIdx.x * kKsCols;
   u32 col[kKsColsPerLane];
   bool col_ok[kKsColsPerLane];
 #pragma unroll
   for (int c = 0; c < kKsColsPerLane; ++c) {
-    col[c] = blockIdx.x * kKsCols + c * 64 + tx;  // lanes read 64 consecutive columns per load
+    col[c] = col0 + c * 64 + tx;
     col_ok[c] = col[c] < width;
   }
+  // staging slot of this thread: column lc of rows lr, lr + 2, ... of a step (a wave covers 64
+  // consecutive columns of one row: coalesced)
+  const u32 lc = threadIdx.x & (kKsCols - 1);
+  const u32 lr = threadIdx.x / kKsCols;
+  const bool lc_ok = col0 + lc < width;
 
   // 64-bit accumulators so that every multiply-add is ONE v_mad_u64_u32; only bits 31..0 are kept
   u64 acc[kKsColsPerLane][kKsPerThread];
@@ -345,6 +363,17 @@ __global__ void __launch_bounds__(256) key_switch_kernel(KsParams Kp, u32 big_n,
   const u32 w_begin = blockIdx.z * words_per_split;  // multiple of kKsWords
   const u32 w_end = (w_begin + words_per_split < big_n) ? w_begin + words_per_split : big_n;
   for (u32 w0 = w_begin; w0 < w_end; w0 += kKsWords) {
+    const u32 rows = ((w_end - w0 < (u32)kKsWords) ? (w_end - w0) : (u32)kKsWords) * levels;
+    const u32* krow = ksk + (size_t)w0 * levels * width + col0;
+    u32 stage[kKsLoads];
+    auto fetch = [&](u32 first_row) {  // rows first_row + lr + 2 i of this chunk -> registers
+#pragma unroll
+      for (int i = 0; i < kKsLoads; ++i) {
+        const u32 r = first_row + lr + (256 / kKsCols) * i;
+        stage[i] = (lc_ok && r < rows) ? krow[(size_t)r * width + lc] : 0u;
+      }
+    };
+    fetch(0);
     // 256 threads decompose 32 samples x 8 words: thread -> (sample = tid / 8, word = tid % 8)
     {
       const int sl = (int)(threadIdx.x >> 3);
@@ -360,20 +389,28 @@ __global__ void __launch_bounds__(256) key_switch_kernel(KsParams Kp, u32 big_n,
         dig[(wl * levels + (levels - 1 - t)) * kKsSamples + sl] = d;
       }
     }
-    __syncthreads();
-    const u32 rows = ((w_end - w0 < (u32)kKsWords) ? (w_end - w0) : (u32)kKsWords) * levels;
-    const u32* krow = ksk + (size_t)w0 * levels * width;
+    // one barrier per step: a step writes buffer (step & 1), which was last read two steps ago, and
+    // every thread has passed the barrier of the step in between since (the first barrier of a chunk
+    // also publishes the digits; the chunk's last one, below, protects them from the next chunk)
+    for (u32 r0 = 0, step = 0; r0 < rows; r0 += kKsKeyRows, ++step) {
+      u32* kt = ktile + (step & 1u) * (kKsKeyRows * kKsCols);
+#pragma unroll
+      for (int i = 0; i < kKsLoads; ++i) kt[(lr + (256 / kKsCols) * i) * kKsCols + lc] = stage[i];
+      __syncthreads();
+      if (r0 + kKsKeyRows < rows) fetch(r0 + kKsKeyRows);  // in flight while this step computes
+      const u32 here = rows - r0 < (u32)kKsKeyRows ? rows - r0 : (u32)kKsKeyRows;
 #pragma unroll 4
-    for (u32 r = 0; r < rows; ++r) {
-      u32 kv[kKsColsPerLane];
+      for (u32 r = 0; r < here; ++r) {
+        u32 kv[kKsColsPerLane];
 #pragma unroll
-      for (int c = 0; c < kKsColsPerLane; ++c) kv[c] = col_ok[c] ? krow[(size_t)r * width + col[c]] : 0u;
-      const u32* d = dig + r * kKsSamples + ty * kKsPerThread;
+        for (int c = 0; c < kKsColsPerLane; ++c) kv[c] = kt[r * kKsCols + c * 64 + tx];
+        const u32* d = dig + (r0 + r) * kKsSamples + ty * kKsPerThread;
 #pragma unroll
-      for (int s = 0; s < kKsPerThread; ++s) {
-        const u32 ds = d[s];  // same address in every lane of the wave: LDS broadcast
+        for (int s = 0; s < kKsPerThread; ++s) {
+          const u32 ds = d[s];  // same address in every lane of the wave: LDS broadcast
 #pragma unroll
-        for (int c = 0; c < kKsColsPerLane; ++c) acc[c][s] = (u64)ds * kv[c] + acc[c][s];
+          for (int c = 0; c < kKsColsPerLane; ++c) acc[c][s] = (u64)ds * kv[c] + acc[c][s];
+        }
       }
     }
     __syncthreads();
@@ -855,11 +892,11 @@ hipError_t external_product(hipStream_t s, int field, const PbsParams& P, const 
 
 hipError_t key_switch(hipStream_t s, const KsParams& K, u32 big_n, u32 n, const u32* lwe_in,
                       size_t batch, const u32* ksk, u32* lwe_out) {
-  const size_t lds = (size_t)kKsWords * K.levels * kKsSamples * sizeof(u32);
+  const size_t lds = ((size_t)kKsWords * K.levels * kKsSamples + 2 * (size_t)kKsKeyRows * kKsCols) * sizeof(u32);
   if (lds > 64 * 1024) return hipErrorInvalidValue;
   dim3 grid((n + 1 + kKsCols - 1) / kKsCols, (unsigned)((batch + kKsSamples - 1) / kKsSamples));
-  // aim at >= 4 workgroups per CU; a split covers a multiple of kKsWords words, at least 64
-  unsigned splits = 1024u / (grid.x * grid.y);
+  // aim at TFHE_KS_TARGET_WGS workgroups; a split covers a multiple of kKsWords words, at least 64
+  unsigned splits = TFHE_KS_TARGET_WGS / (grid.x * grid.y);
   const unsigned max_splits = (big_n + 63u) / 64u;
   if (splits > max_splits) splits = max_splits;
   if (splits > 32u) splits = 32u;
