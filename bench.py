@@ -161,8 +161,12 @@ def bench_external_product(args, pkg, params, batch, dev, rand_words, world, ran
             dist.barrier()
         torch.cuda.synchronize()
 
-    steps = max(args.steps, 20)
-    for _ in range(max(args.warmup, 3)):
+    # One launch is ~0.1 ms: a handful of launches runs on a chip that has not reached its sustained clocks
+    # (20 launches after 3 of warm-up measured 0.123 ms per launch, 200 after 300 measured 0.103 ms, 1000
+    # after 1000 the same 0.103 ms).  So: at least 300 untimed launches, at least 200 timed ones.
+    steps = max(args.steps, 200)
+    warmup = max(args.warmup, 300)
+    for _ in range(warmup):
         ctx.external_product_prepared(prepared, glwe, out=out)
     barrier()
     kms = []
@@ -200,7 +204,7 @@ def bench_external_product(args, pkg, params, batch, dev, rand_words, world, ran
     hbm_copy = measure_hbm_copy_gbs(torch, dev, ctx=ctx)
     result = {
         "metric": "external_products_per_sec", "value": batch * world * steps / dt, "unit": "products/s",
-        "n_gpus": world, "steps": steps, "warmup": max(args.warmup, 3), "ms_per_step": dt / steps * 1e3,
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64" if ctx.backend.startswith("fp64") else "u64", "data": "synthetic",
         "config": {"workload": f"external_product {args.workload}: batch {batch}/GPU, N={params.N}, k={params.k}, "
