@@ -12,6 +12,8 @@
   fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
 
 constexpr int ITERS = 2048;
+constexpr int kWarmupLaunches = 200;  // >= 15 ms of work before anything is timed
+constexpr int kTimedLaunches = 20;
 constexpr int UNROLL = 16;   // instructions per loop body (8 independent chains x 2)
 
 #define R8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
@@ -211,12 +213,15 @@ int main() {
     for (int wps : {1, 2, 4, 8}) {
       // one block of 256 threads = 1 wave per SIMD on a CU; wps blocks per CU
       int blocks = cus * wps;
-      e.k<<<blocks, 256>>>(out, 1);  // warmup
+      // warm-up: one launch is 0.07-2.5 ms; the chip only reaches its sustained clocks after tens of
+      // milliseconds of work (round 1 timed the second launch and read every rate ~15 % too slow)
+      for (int i = 0; i < kWarmupLaunches; ++i) e.k<<<blocks, 256>>>(out, 1);
       CHECK(hipDeviceSynchronize());
       CHECK(hipEventRecord(e0));
-      e.k<<<blocks, 256>>>(out, 2);
+      for (int i = 0; i < kTimedLaunches; ++i) e.k<<<blocks, 256>>>(out, 2);
       CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
       float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+      ms /= kTimedLaunches;
       const bool two = std::string(e.name).find("x2 instr") != std::string::npos;
       double winstr_per_simd = (double)ITERS * UNROLL * wps * (two ? 2 : 1);   // wave-instructions issued per SIMD
       double ns = ms * 1e6 / winstr_per_simd;

@@ -14,10 +14,11 @@ d, label, batch, n, algo_bytes = sys.argv[1], sys.argv[2], int(sys.argv[3]), int
 want = sys.argv[sys.argv.index("--kernel") + 1] if "--kernel" in sys.argv else "blind_rotate"
 source = sys.argv[sys.argv.index("--source") + 1] if "--source" in sys.argv else ""
 # issue floor of the cfg2 kernel's instruction mix at 2 waves per SIMD, from the per-instruction rates of
-# profiles/r02_valu_issue_rates_gfx950.txt (v_fma_f64 5.09, v_mul_f64 4.99, v_add_f64 4.82, v_rndne_f64 4.37,
-# 32-bit integer ops ~4.5) weighted with the shipped kernel's mix (profiles/r02_*_isa_blind_rotate_loops.txt:
-# per wave and iteration 1200 fma, 1140 mul, 1472 add, 584 rndne, 48 cvt, 643 integer)
-FLOOR = (1200 * 5.09 + 1140 * 4.99 + 1472 * 4.82 + 584 * 4.37 + 48 * 5.0 + 643 * 4.5) / 5087
+# profiles/r02_valu_issue_rates_gfx950.txt (warm clocks: v_fma_f64 4.78, v_mul_f64 4.48, v_add_f64 4.48,
+# v_rndne_f64 4.34, 32-bit integer ops ~4.4) weighted with the shipped kernel's mix
+# (profiles/r02_d_isa_blind_rotate_loops.txt: per wave and iteration 1200 fma, 1140 mul, 1472 add, 584 rndne,
+# 48 cvt, 643 integer)
+FLOOR = (1200 * 4.78 + 1140 * 4.48 + 1472 * 4.48 + 584 * 4.34 + 48 * 4.8 + 643 * 4.4) / 5087
 tot = defaultdict(float)
 launches = defaultdict(set)
 kernel = None
