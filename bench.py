@@ -250,6 +250,10 @@ def main():
     ap.add_argument("--scatter-gather", action="store_true",
                     help="include the RCCL scatter of the input batch from rank 0 and the gather of the results "
                          "in every step (tfhe_research_amd.sharding); default: shards are resident per rank")
+    ap.add_argument("--scatter-gather-figure", action="store_true",
+                    help="N > 1: after the timed region, also time the step with rank 0 owning the whole batch and add it "
+                         "to the line as `scatter_gather` (never `value`).  Off by default: the headline line must not "
+                         "depend on an optional point-to-point exchange")
     ap.add_argument("--gate", default="", choices=["", "nand", "and", "or", "xor"],
                     help="step = one homomorphic gate over the batch (boolean.rs: bootstrap(2*ct1 + ct0)) instead of a plain PBS")
     args = ap.parse_args()
@@ -264,6 +268,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    if os.environ.get("TFHE_BENCH_BACKEND", "nccl") != "nccl":
+        local_rank %= torch.cuda.device_count()  # rehearsal: ranks share the GPUs that exist
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # one process per GPU; under torch.distributed.run the group is created even for a single rank so
@@ -272,7 +278,13 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # TFHE_BENCH_BACKEND=gloo: rehearsal of the N > 1 code path with several ranks on ONE GPU (RCCL refuses
+        # two ranks per device); the measured configuration is always nccl = RCCL
+        dist_backend = os.environ.get("TFHE_BENCH_BACKEND", "nccl")
+        if dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(dist_backend, rank=rank, world_size=world)
 
     pkg = entry.load_package()
     k, logn, n, pbs, ks, log_p, default_batch = WORKLOADS[args.workload]
@@ -301,7 +313,7 @@ def main():
         bsk, ksk = sharding.replicate_keys(held, [params.bsk_shape(), params.ksk_shape()], root=0, like=lwe)
         torch.cuda.synchronize()
         del held
-        key_replication = (f"BSK+KSK drawn on rank 0 and broadcast over RCCL to {world} ranks "
+        key_replication = (f"BSK+KSK drawn on rank 0 and broadcast over {'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()} to {world} ranks "
                            f"({(bsk.numel() + ksk.numel()) * 4 / 1e6:.0f} MB, {time.perf_counter() - t_rep:.2f} s incl. generation)")
     else:
         bsk = rand_words(*params.bsk_shape())
@@ -415,7 +427,7 @@ def main():
             "note": "VALU-issue bound by design (SURVEY 8d): the key is shared by the batch and stays in L2/Infinity Cache; HBM fraction reported as the metric asks",
         },
     }
-    if use_dist and world > 1 and not args.scatter_gather and not args.gate:
+    if use_dist and world > 1 and args.scatter_gather_figure and not args.scatter_gather and not args.gate:
         # second figure, outside the timed region above: the same step with rank 0 owning the whole
         # batch -- RCCL scatter of [B/N][n+1] rows, local bootstrap, gather (sharding.bootstrap_sharded)
         import importlib

@@ -90,8 +90,8 @@ struct FpField {
   // product is below 2^41 * 2^9 = 2^50, the sum of four below 2^52, and the butterfly's other leg
   // (a radix4_small output) below 2^51.6: outputs stay below 2^52.8 < 2^53 -- exact integers, no
   // reduction.  4 instructions.
-  TFHE_HD static elem radix8_small_v(elem a, elem b, elem c, elem d, const elem* k) {
-    return __builtin_fma(k[3], d, __builtin_fma(k[2], c, __builtin_fma(k[1], b, k[0] * a)));
+  TFHE_HD static elem radix8_small_v(elem a, elem b, elem c, elem d, elem k0, elem k1, elem k2, elem k3) {
+    return __builtin_fma(k3, d, __builtin_fma(k2, c, __builtin_fma(k1, b, k0 * a)));
   }
   // x -> balanced residue, |x| < 2^53
   TFHE_HD static elem reduce(elem x) { return __builtin_fma(-__builtin_rint(x * PINV), P, x); }

@@ -81,7 +81,7 @@ struct Fp49Field {
   TFHE_HD static elem mul_small(elem a, elem w) { return mul(a, w); }
   static constexpr bool kFuseFirstTwo = false;
   TFHE_HD static void radix4_small(elem&, elem&, elem&, elem&, elem, elem, elem, elem, elem) {}
-  TFHE_HD static elem radix8_small_v(elem, elem, elem, elem, const elem*) { return 0.0; }
+  TFHE_HD static elem radix8_small_v(elem, elem, elem, elem, elem, elem, elem, elem) { return 0.0; }
   // x -> balanced residue, |x| < 2^53
   TFHE_HD static elem reduce(elem x) { return __builtin_fma(-__builtin_rint(x * PINV), P, x); }
   TFHE_HD static elem from_digit(u32 d) { return (double)(i32)d; }

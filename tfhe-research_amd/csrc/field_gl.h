@@ -33,7 +33,7 @@ struct GlFieldT {
   TFHE_HD static elem mul_small(elem a, elem w) { return gl::mul(a, w); }
   static constexpr bool kFuseFirstTwo = false;  // canonical u64 arithmetic gains nothing from it
   TFHE_HD static void radix4_small(elem&, elem&, elem&, elem&, elem, elem, elem, elem, elem) {}
-  TFHE_HD static elem radix8_small_v(elem, elem, elem, elem, const elem*) { return 0; }
+  TFHE_HD static elem radix8_small_v(elem, elem, elem, elem, elem, elem, elem, elem) { return 0; }
   // gadget digit (wrapped u32 holding a small signed integer) -> field element
   TFHE_HD static elem from_digit(u32 d) { return gl::from_i32(d); }
   // key word -> field element of spectrum `part`

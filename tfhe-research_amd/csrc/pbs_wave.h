@@ -145,6 +145,9 @@ TFHE_HD u32 monomial_coeff(const u32* poly, int j, u32 m) {
 // notes/BMMP Bootstrapping.md needs three products of the same accumulator).  out(m, j, value) is
 // called for key m = 0 .. KEYS-1 in turn, end_of_key(m) once after the last coefficient of key m.
 // ---------------------------------------------------------------------------------------------
+#ifndef TFHE_TOP_PREFETCH
+#define TFHE_TOP_PREFETCH 1
+#endif
 template <class F, int LOGN, int K, int G, int KEYS, class Ctx, class Src, class Out, class EndKey>
 TFHE_HD void external_product_team_keys(const Ctx& c, const PbsParams& P, const typename F::elem* ggsw,
                                         size_t ggsw_words, Src src, Out out, EndKey end_of_key) {
@@ -174,9 +177,15 @@ TFHE_HD void external_product_team_keys(const Ctx& c, const PbsParams& P, const 
   // the lowest kept limb (whose carry-in is 0 by construction)
   // v[r]: rounded coefficient; once a limb has been consumed its bit log_base-1 carries the digit
   // chain's carry to the next limb (decompose_limb_fast)
+  // The lane-uniform constants of the forward transforms' top window (wave_ntt.h::TopConsts) are fetched
+  // while the operand is read and rounded, stay in scalar registers for all levels, and make room for
+  // the inverse transforms' block after the last level.
+  TopConsts<F, LOGN, G, true> ftop;
+  if constexpr (TFHE_TOP_PREFETCH) ftop.issue(c.twiddles_uniform());
   u32 v[E];
 #pragma unroll
   for (int r = 0; r < E; ++r) v[r] = round_value(src(r * T + lane), P.ignored_bits);
+  if constexpr (TFHE_TOP_PREFETCH) ftop.ready();
 
   // Key tiles of one level for my column: idx = s * PARTS + q, s = source polynomial 0..K, q = part.
   // A tile is consumed in chunks of CH registers (order: s, piece of the spectrum, q); chunks are staged
@@ -231,7 +240,10 @@ TFHE_HD void external_product_team_keys(const Ctx& c, const PbsParams& P, const 
       // digits are tiny (|d| <= B <= 2^F::kSmallBits, enforced when the context picks the field):
       // the first butterfly stage uses F::mul_small.  A team barrier precedes every level (the
       // caller's for level 0, the previous level's below) and nobody reads this buffer after it.
-      ntt_forward<F, LOGN, G, true, true>(cl, work);
+      if constexpr (TFHE_TOP_PREFETCH)
+        ntt_forward<F, LOGN, G, true, true>(cl, work, ftop);
+      else
+        ntt_forward<F, LOGN, G, true, true>(cl, work);
       if (F::kReduceSpectrum) {  // little lazy headroom: MAC terms must start from |d| <= p/2
 #pragma unroll
         for (int r = 0; r < E; ++r) work[r] = F::reduce(work[r]);
@@ -276,6 +288,8 @@ TFHE_HD void external_product_team_keys(const Ctx& c, const PbsParams& P, const 
   }
 
   const Ctx ci = c.with_exchange_buffer(two ? (int)(P.levels & 1u) : 0);
+  TopConsts<F, LOGN, G, false> itop;  // arrives during the first two passes of the first inverse transform
+  if constexpr (TFHE_TOP_PREFETCH) itop.issue(c.twiddles_uniform());
   static_for<0, KEYS>([&](auto key_c) {
     constexpr int m = decltype(key_c)::value;
     static_for<0, PARTS>([&](auto part_c) {
@@ -284,7 +298,12 @@ TFHE_HD void external_product_team_keys(const Ctx& c, const PbsParams& P, const 
       for (int r = 0; r < E; ++r)
         accum[q][r] = SPLIT ? F::mac_finish(accum[q][r], accum_lo[SPLIT ? q : 0][SPLIT ? r : 0])
                             : F::before_inverse(accum[q][r]);
-      ntt_inverse<F, LOGN, G>(ci, accum[q]);
+      if constexpr (TFHE_TOP_PREFETCH) {
+        if constexpr (q == 0) itop.ready();  // nothing else is in flight here: the wait is for the block alone
+        ntt_inverse<F, LOGN, G>(ci, accum[q], itop);
+      }
+      else
+        ntt_inverse<F, LOGN, G>(ci, accum[q]);
     });
 #pragma unroll
     for (int r = 0; r < E; ++r) {

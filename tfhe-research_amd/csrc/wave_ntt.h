@@ -111,6 +111,119 @@ TFHE_HD void ntt_stage_twiddles(Elem* dst, const Elem* src, int tid, int nthread
   for (int i = tid; i < ntt_twiddle_words(1 << LOGN); i += nthreads) dst[ntt_twiddle_slot<LOGN, G>(i)] = src[i];
 }
 
+// ---------------------------------------------------------------------------------------------
+// Lane-uniform constants of the TOP register window, fetched ahead of their use.
+// In the top window hi = 0: every lane uses the same twiddles (and the same fused-stage constants), so
+// on the GPU they are scalar operands (SGPRs) of the fp64 instructions.  Left to the compiler, their
+// scalar loads sit inside the loops right in front of the first use -- the workgroup barriers forbid
+// hoisting them -- and every `s_waitcnt lgkmcnt(0)` that follows also waits for whatever LDS reads of a
+// transpose are in flight (scalar loads return out of order, so the counter has to drain): a dozen
+// exposed round trips per wave and CMUX iteration (profiles/r02_*_isa_*).  TopConsts issues the loads
+// explicitly, long before the pass that needs them (issue()), and waits once at a point where nothing
+// else is outstanding (ready()).  The compiler does not know about the loads in flight; that is safe:
+// an extra outstanding scalar load only makes the LDS waits it inserts itself more conservative, and no
+// value of a block is used before ready() (the blocks are asm outputs of issue() and in/out operands of
+// ready()).  The host emulator copies the values.
+// ---------------------------------------------------------------------------------------------
+template <class Elem, int CNT>
+struct UniformBlock {
+  static_assert(CNT == 2 || CNT == 4 || CNT == 8, "4, 8 or 16 dwords");
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef Elem vec __attribute__((ext_vector_type(CNT)));
+  vec v;
+  template <int FIRST>
+  __device__ __forceinline__ void issue(const Elem* table) {
+    if constexpr (CNT == 8)
+      asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(v) : "s"(table), "i"(FIRST * 8));
+    else if constexpr (CNT == 4)
+      asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(v) : "s"(table), "i"(FIRST * 8));
+    else
+      asm volatile("s_load_dwordx4 %0, %1, %2" : "=s"(v) : "s"(table), "i"(FIRST * 8));
+  }
+  __device__ __forceinline__ void pin() { asm volatile("" : "+s"(v)); }
+#else
+  Elem v[CNT];
+  template <int FIRST>
+  void issue(const Elem* table) {
+    for (int i = 0; i < CNT; ++i) v[i] = table[FIRST + i];
+  }
+  void pin() {}
+#endif
+  TFHE_HD Elem operator[](int i) const { return v[i]; }
+};
+
+TFHE_HD void uniform_wait() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+}
+
+// the top window's constants read straight from the table (the compiler places the loads)
+template <class Elem>
+struct TopFromTable {
+  const Elem* twu;
+  int n;
+  TFHE_HD Elem tw(int i) const { return twu[i]; }
+  TFHE_HD Elem fused(int i) const { return twu[n + i]; }
+};
+
+// ... prefetched.  FORWARD_SMALL: the forward transform of gadget digits, whose first two or three
+// stages are fused in fields with kFuseFirstTwo (constants at [N ..]); otherwise plain stages only
+// (any inverse transform; forward transforms of fields without fused stages).  Plain stage s of the
+// window reads psi_rev[2^s .. 2^(s+1)), s < e = log2(E).
+template <class F, int LOGN, int G, bool FORWARD_SMALL>
+struct TopConsts {
+  typedef typename F::elem elem;
+  static constexpr int E = NttShape<LOGN, G>::kE;
+  static constexpr int e = NttShape<LOGN, G>::kEBits;
+  static constexpr int N = 1 << LOGN;
+  static constexpr bool FUSE = FORWARD_SMALL && F::kFuseFirstTwo && e >= 2;
+  static constexpr bool FUSE3 = TFHE_RADIX8 && FUSE && e >= 3;
+  static constexpr int kFirstPlain = FUSE3 ? 8 : FUSE ? 4 : 1;  // lowest table index a plain stage reads
+  UniformBlock<elem, 4> lo;       // [0, 4): psi_rev[1..3]
+  UniformBlock<elem, 4> mid;      // [4, 8)
+  UniformBlock<elem, 8> hi[3];    // [8, 16), [16, 24), [24, 32)
+  UniformBlock<elem, 8> fa, fb;   // [N, N+8), [N+8, N+16)
+  UniformBlock<elem, 2> fc;       // [N+16, N+18)   (FUSE without the radix-8 step: fc holds [N, N+2))
+  TFHE_HD void issue(const elem* table) {
+    lo.template issue<0>(table);
+    if constexpr (E > 4 && kFirstPlain < 8) mid.template issue<4>(table);
+    if constexpr (E > 8) hi[0].template issue<8>(table);
+    if constexpr (E > 16) {
+      hi[1].template issue<16>(table);
+      hi[2].template issue<24>(table);
+    }
+    if constexpr (FUSE3) {
+      fa.template issue<N>(table);
+      fb.template issue<N + 8>(table);
+      fc.template issue<N + 16>(table);
+    } else if constexpr (FUSE) {
+      fc.template issue<N>(table);
+    }
+  }
+  // before the first tw()/fused(): call where no LDS read is in flight that is not needed anyway
+  TFHE_HD void ready() {
+    uniform_wait();
+    lo.pin();
+    if constexpr (E > 4 && kFirstPlain < 8) mid.pin();
+    if constexpr (E > 8) hi[0].pin();
+    if constexpr (E > 16) {
+      hi[1].pin();
+      hi[2].pin();
+    }
+    if constexpr (FUSE3) {
+      fa.pin();
+      fb.pin();
+    }
+    if constexpr (FUSE) fc.pin();
+  }
+  TFHE_HD elem tw(int i) const { return i < 4 ? lo[i] : i < 8 ? mid[i - 4] : hi[(i - 8) >> 3][(i - 8) & 7]; }
+  TFHE_HD elem fused(int i) const {
+    if constexpr (FUSE3) return i < 8 ? fa[i] : i < 16 ? fb[i - 8] : fc[i - 16];
+    return fc[i];
+  }
+};
+
 // XOR swizzle of the transpose buffer (element = 8 bytes).  Each one makes every ds_write_b64 and
 // ds_read_b64 of both transposes, in both directions, bank-conflict free (tools/ntt_model.py).
 template <int LOGN, int G>
@@ -187,8 +300,8 @@ TFHE_HD void ntt_transpose(const Ctx& c, typename F::elem (&x)[NttShape<LOGN, G>
 // forward stages on bits BHI..BLO (descending) of window [LO, LO+e).  SMALL_FIRST: the inputs of
 // the first stage handled here are small integers (gadget digits), so its twiddle products may
 // use F::mul_small (exact without reduction in the fp64 field).
-template <class F, int LOGN, int G, int LO, int BHI, int BLO, bool SMALL_FIRST, class Ctx>
-TFHE_HD void ntt_pass_forward(const Ctx& c, typename F::elem (&x)[NttShape<LOGN, G>::kE]) {
+template <class F, int LOGN, int G, int LO, int BHI, int BLO, bool SMALL_FIRST, class Ctx, class Top>
+TFHE_HD void ntt_pass_forward(const Ctx& c, typename F::elem (&x)[NttShape<LOGN, G>::kE], const Top& top) {
   typedef typename F::elem elem;
   constexpr int E = NttShape<LOGN, G>::kE;
   constexpr int e = NttShape<LOGN, G>::kEBits;
@@ -200,7 +313,6 @@ TFHE_HD void ntt_pass_forward(const Ctx& c, typename F::elem (&x)[NttShape<LOGN,
   // SGPRs -- no LDS reads, no vector registers; the fp64 instructions take them as their one scalar
   // operand), the lower windows from the working copy (LDS).
   constexpr bool TOP = LO == NttShape<LOGN, G>::kTBits;
-  const elem* twu = c.twiddles_uniform();
   const int hi = c.tid() >> LO;
   // The top stages of the whole transform on small inputs (gadget digits): in a field with
   // kFuseFirstTwo the first two collapse into one exact radix-4 step without any modular reduction
@@ -213,7 +325,7 @@ TFHE_HD void ntt_pass_forward(const Ctx& c, typename F::elem (&x)[NttShape<LOGN,
   if constexpr (FUSE) {
     constexpr int s1 = 1 << (BHI - LO), s2 = s1 >> 1, s3 = s2 >> 1;
     static_assert(!FUSE || TOP, "the fused stages are the top ones");
-    const elem w1 = twu[1], w2a = twu[2], w2b = twu[3], w12a = twu[N], w12b = twu[N + 1];
+    const elem w1 = top.tw(1), w2a = top.tw(2), w2b = top.tw(3), w12a = top.fused(0), w12b = top.fused(1);
     if constexpr (FUSE3) {
 #pragma unroll
       for (int r = 0; r < s3; ++r) {
@@ -222,7 +334,8 @@ TFHE_HD void ntt_pass_forward(const Ctx& c, typename F::elem (&x)[NttShape<LOGN,
         constexpr int pos[4] = {0, s2, s1, s1 + s2};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const elem z = F::radix8_small_v(va, vb, vc, vd, twu + N + 2 + 4 * q);
+          const elem z = F::radix8_small_v(va, vb, vc, vd, top.fused(2 + 4 * q), top.fused(3 + 4 * q),
+                                           top.fused(4 + 4 * q), top.fused(5 + 4 * q));
           const elem u = x[r + pos[q]];
           x[r + pos[q]] = F::add(u, z);
           x[r + pos[q] + s3] = F::sub(u, z);
@@ -242,7 +355,7 @@ TFHE_HD void ntt_pass_forward(const Ctx& c, typename F::elem (&x)[NttShape<LOGN,
     for (int r0 = 0; r0 < E; ++r0) {
       if ((r0 >> rb) & 1) continue;
       const int r1 = r0 | (1 << rb);
-      const elem w = TOP ? twu[m + (r0 >> (rb + 1))]
+      const elem w = TOP ? top.tw(m + (r0 >> (rb + 1)))
                      : TFHE_TW_TRANSPOSED ? tw[m + (r0 >> (rb + 1)) * H + hi]
                                           : tw[m + (hi << (LO + e - b - 1)) + (r0 >> (rb + 1))];
       const elem u = x[r0];
@@ -254,15 +367,14 @@ TFHE_HD void ntt_pass_forward(const Ctx& c, typename F::elem (&x)[NttShape<LOGN,
 }
 
 // inverse stages on bits BLO..BHI (ascending) of window [LO, LO+e)
-template <class F, int LOGN, int G, int LO, int BHI, int BLO, class Ctx>
-TFHE_HD void ntt_pass_inverse(const Ctx& c, typename F::elem (&x)[NttShape<LOGN, G>::kE]) {
+template <class F, int LOGN, int G, int LO, int BHI, int BLO, class Ctx, class Top>
+TFHE_HD void ntt_pass_inverse(const Ctx& c, typename F::elem (&x)[NttShape<LOGN, G>::kE], const Top& top) {
   typedef typename F::elem elem;
   constexpr int E = NttShape<LOGN, G>::kE;
   constexpr int e = NttShape<LOGN, G>::kEBits;
   constexpr int H = 1 << (NttShape<LOGN, G>::kTBits - LO);
   constexpr bool TOP = LO == NttShape<LOGN, G>::kTBits;  // lane-uniform twiddles: see ntt_pass_forward
   const elem* tw = c.twiddles();
-  const elem* twu = c.twiddles_uniform();
   const int hi = c.tid() >> LO;
 #pragma unroll
   for (int b = BLO; b <= BHI; ++b) {
@@ -275,7 +387,7 @@ TFHE_HD void ntt_pass_inverse(const Ctx& c, typename F::elem (&x)[NttShape<LOGN,
     for (int r0 = 0; r0 < E; ++r0) {
       if ((r0 >> rb) & 1) continue;
       const int r1 = r0 | (1 << rb);
-      const elem w = TOP ? twu[2 * h - 1 - (r0 >> (rb + 1))]
+      const elem w = TOP ? top.tw(2 * h - 1 - (r0 >> (rb + 1)))
                      : TFHE_TW_TRANSPOSED ? tw[h + (cnt - 1 - (r0 >> (rb + 1))) * H + (H - 1 - hi)]
                                           : tw[2 * h - 1 - (hi << (LO + e - b - 1)) - (r0 >> (rb + 1))];
       const elem u = x[r0];
@@ -297,33 +409,48 @@ TFHE_HD void ntt_pass_inverse(const Ctx& c, typename F::elem (&x)[NttShape<LOGN,
 // in: x[r] = a[r*64G + tid].  out: x[r] = A_bitrev[tid*E + r].
 // SMALL_INPUT: every |x[r]| <= 2^F::kSmallBits on entry (gadget digits).
 // AFTER_BARRIER: nobody has read the buffer since the last workgroup barrier (see ntt_transpose).
-template <class F, int LOGN, int G, bool SMALL_INPUT = false, bool AFTER_BARRIER = false, class Ctx>
-TFHE_HD void ntt_forward(const Ctx& c, typename F::elem (&x)[NttShape<LOGN, G>::kE]) {
+// top: where the top window's lane-uniform constants come from (TopFromTable, or a TopConsts the
+// caller has issued earlier and on which ready() has been called).
+template <class F, int LOGN, int G, bool SMALL_INPUT = false, bool AFTER_BARRIER = false, class Ctx, class Top>
+TFHE_HD void ntt_forward(const Ctx& c, typename F::elem (&x)[NttShape<LOGN, G>::kE], const Top& top) {
   using S = NttShape<LOGN, G>;
-  ntt_pass_forward<F, LOGN, G, S::kLo1, LOGN - 1, S::kTBits, SMALL_INPUT>(c, x);
+  ntt_pass_forward<F, LOGN, G, S::kLo1, LOGN - 1, S::kTBits, SMALL_INPUT>(c, x, top);
   ntt_transpose<F, LOGN, G, S::kLo1, S::kLo2, AFTER_BARRIER>(c, x);
-  ntt_pass_forward<F, LOGN, G, S::kLo2, S::kTBits - 1, S::kLo2, false>(c, x);
+  ntt_pass_forward<F, LOGN, G, S::kLo2, S::kTBits - 1, S::kLo2, false>(c, x, top);
   ntt_transpose<F, LOGN, G, S::kLo2, S::kLo3>(c, x);
-  ntt_pass_forward<F, LOGN, G, S::kLo3, S::kLo2 - 1, S::kLo3, false>(c, x);
+  ntt_pass_forward<F, LOGN, G, S::kLo3, S::kLo2 - 1, S::kLo3, false>(c, x, top);
   if constexpr (S::kPasses == 4) {
     ntt_transpose<F, LOGN, G, S::kLo3, S::kLo4>(c, x);
-    ntt_pass_forward<F, LOGN, G, S::kLo4, S::kLo3 - 1, 0, false>(c, x);
+    ntt_pass_forward<F, LOGN, G, S::kLo4, S::kLo3 - 1, 0, false>(c, x, top);
   }
 }
 
+template <class F, int LOGN, int G, bool SMALL_INPUT = false, bool AFTER_BARRIER = false, class Ctx>
+TFHE_HD void ntt_forward(const Ctx& c, typename F::elem (&x)[NttShape<LOGN, G>::kE]) {
+  const TopFromTable<typename F::elem> top{c.twiddles_uniform(), 1 << LOGN};
+  ntt_forward<F, LOGN, G, SMALL_INPUT, AFTER_BARRIER>(c, x, top);
+}
+
 // in: x[r] = A_bitrev[tid*E + r].  out: x[r] = N * a[r*64G + tid] (unscaled inverse).
-template <class F, int LOGN, int G, class Ctx>
-TFHE_HD void ntt_inverse(const Ctx& c, typename F::elem (&x)[NttShape<LOGN, G>::kE]) {
+// A prefetched `top` must be ready() before the call.
+template <class F, int LOGN, int G, class Ctx, class Top>
+TFHE_HD void ntt_inverse(const Ctx& c, typename F::elem (&x)[NttShape<LOGN, G>::kE], const Top& top) {
   using S = NttShape<LOGN, G>;
   if constexpr (S::kPasses == 4) {
-    ntt_pass_inverse<F, LOGN, G, S::kLo4, S::kLo3 - 1, 0>(c, x);
+    ntt_pass_inverse<F, LOGN, G, S::kLo4, S::kLo3 - 1, 0>(c, x, top);
     ntt_transpose<F, LOGN, G, S::kLo4, S::kLo3>(c, x);
   }
-  ntt_pass_inverse<F, LOGN, G, S::kLo3, S::kLo2 - 1, S::kLo3>(c, x);
+  ntt_pass_inverse<F, LOGN, G, S::kLo3, S::kLo2 - 1, S::kLo3>(c, x, top);
   ntt_transpose<F, LOGN, G, S::kLo3, S::kLo2>(c, x);
-  ntt_pass_inverse<F, LOGN, G, S::kLo2, S::kTBits - 1, S::kLo2>(c, x);
+  ntt_pass_inverse<F, LOGN, G, S::kLo2, S::kTBits - 1, S::kLo2>(c, x, top);
   ntt_transpose<F, LOGN, G, S::kLo2, S::kLo1>(c, x);
-  ntt_pass_inverse<F, LOGN, G, S::kLo1, LOGN - 1, S::kTBits>(c, x);
+  ntt_pass_inverse<F, LOGN, G, S::kLo1, LOGN - 1, S::kTBits>(c, x, top);
+}
+
+template <class F, int LOGN, int G, class Ctx>
+TFHE_HD void ntt_inverse(const Ctx& c, typename F::elem (&x)[NttShape<LOGN, G>::kE]) {
+  const TopFromTable<typename F::elem> top{c.twiddles_uniform(), 1 << LOGN};
+  ntt_inverse<F, LOGN, G>(c, x, top);
 }
 
 }  // namespace tfhe

@@ -1,4 +1,5 @@
-"""Dev helper (GPU box): kernel timings of a dev build for one workload shape. usage: dev_bench.py cfg2|cfg3"""
+"""Dev helper (GPU box): kernel timings of a dev build for one workload shape. usage: dev_bench.py cfg2|cfg3|cfg5
+(DEV_BACKEND=BACKEND_AUTO|BACKEND_FP64|BACKEND_FP64_P49|... picks the field, default BACKEND_FP64)"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,13 +10,14 @@ m = g.load_package()
 from oracle import oracle as orc
 orc.set_poly_mul_mode(1)
 which = sys.argv[1]
+BACKEND = getattr(m, os.environ.get('DEV_BACKEND', 'BACKEND_FP64'))
 cfg = {"cfg2": (1, 10, 630, (7, 3), 4096), "cfg3": (2, 9, 722, (4, 6), 4096), "cfg5": (2, 11, 630, (8, 4), 1024)}[which]
 k, logn, n, pbs, batch = cfg
 # parity on a short key first
 ps = orc.Params(k, logn, 4, orc.Decomposer(*pbs)); pp = m.TfheParams(k, logn, 4, m.DecomposerParams(*pbs))
 lwe, bsk, ksk, tv = orc.synthetic_inputs(ps, 5, cfg_index=3)
 want = np.stack([orc.bootstrap(ps, lwe[b], bsk, ksk, tv) for b in range(5)])
-with m.Context(pp, backend=m.BACKEND_FP64) as ctx:
+with m.Context(pp, backend=BACKEND) as ctx:
     ctx.load_bootstrapping_key(bsk, ksk); ok = bool(np.array_equal(ctx.bootstrap(lwe, tv), want))
 P = m.TfheParams(k, logn, n, m.DecomposerParams(*pbs))
 dev = torch.device("cuda", 0)
@@ -23,7 +25,7 @@ gen = torch.Generator(device=dev); gen.manual_seed(1)
 rw = lambda *s: torch.randint(-(1 << 31), (1 << 31) - 1, s, dtype=torch.int32, device=dev, generator=gen)
 lw, bk, kk = rw(batch, n + 1), rw(*P.bsk_shape()), rw(*P.ksk_shape())
 tvd = torch.from_numpy(m.construct_identity_test_vector(P).astype(np.int32)).to(dev)
-ctx = m.Context(P, backend=m.BACKEND_FP64); ctx.use_torch_stream(); ctx.load_bootstrapping_key(bk, kk); ctx.reserve(batch); ctx.set_timing(True)
+ctx = m.Context(P, backend=BACKEND); ctx.use_torch_stream(); ctx.load_bootstrapping_key(bk, kk); ctx.reserve(batch); ctx.set_timing(True)
 out = torch.empty_like(lw)
 ctx.bootstrap(lw, tvd, out=out); torch.cuda.synchronize()
 ts = []
