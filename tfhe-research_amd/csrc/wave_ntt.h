@@ -106,9 +106,26 @@ TFHE_HD int ntt_twiddle_slot(int idx) {
 }
 
 // copy the natural-order table `src` (ntt_twiddle_words(N) elements) into the working copy `dst`
+// (eight loads in flight per thread: one load, wait, store per trip made the copy a chain of nine global
+// round trips at the start of every team -- several microseconds, which the persistent external-product
+// kernel pays once per four products at batch 4096)
 template <int LOGN, int G, class Elem>
 TFHE_HD void ntt_stage_twiddles(Elem* dst, const Elem* src, int tid, int nthreads) {
-  for (int i = tid; i < ntt_twiddle_words(1 << LOGN); i += nthreads) dst[ntt_twiddle_slot<LOGN, G>(i)] = src[i];
+  constexpr int W = ntt_twiddle_words(1 << LOGN);
+  constexpr int U = 8;
+  for (int base = tid; base < W; base += U * nthreads) {
+    Elem tmp[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = base + u * nthreads;
+      tmp[u] = src[i < W ? i : 0];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = base + u * nthreads;
+      if (i < W) dst[ntt_twiddle_slot<LOGN, G>(i)] = tmp[u];
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
