@@ -91,13 +91,18 @@ int tfhe_params_validate(const tfhe_params *params);
 #define TFHE_BACKEND_FP64 2
 #define TFHE_BACKEND_GOLDILOCKS_SPLIT 3
 #define TFHE_BACKEND_FP64_P49 4
+/* FP64_FFT: the negacyclic product through a complex FFT in fp64 (N/2 points, two coefficients per element,
+ *            key split into 16-bit halves), exact by a proven bound on the rounding error of every output
+ *            coefficient (csrc/field_fft.h: 3.1 n eta R M^1.5 |x| |y| < 1/4, e.g. 0.011 at N = 1024, k = 1,
+ *            l = 3, log_base = 7); kernels at N = 1024.  Same bits as the exact-NTT fields. */
+#define TFHE_BACKEND_FP64_FFT 5
 
 /* Creates a context bound to HIP device `device`.  Fails with TFHE_ERR_NO_DEVICE when no GPU is
  * present: there is deliberately no CPU path behind this ABI. */
 int tfhe_context_create(const tfhe_params *params, int device, tfhe_context **out);
 int tfhe_context_create_with_backend(const tfhe_params *params, int device, int backend,
                                      tfhe_context **out);
-/* "fp64-p49", "fp64-p42", "goldilocks" or "goldilocks-split" */
+/* "fp64-fft", "fp64-p49", "fp64-p42", "goldilocks" or "goldilocks-split" */
 const char *tfhe_context_backend(const tfhe_context *ctx);
 void tfhe_context_destroy(tfhe_context *ctx);
 /* Run on an existing hipStream_t, e.g. torch.cuda.current_stream().cuda_stream.  A NULL handle is

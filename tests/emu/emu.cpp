@@ -24,6 +24,7 @@ int g_exchange_buffers = 1;  // exchange buffers per group (kernels.hip::Exchang
 template <class Elem>
 struct HostTeam {
   int n, g;  // ring degree, waves per polynomial group
+  int ns;    // transform elements per polynomial (n, or n/2 for the complex transform)
   int exb, groups;
   std::vector<Elem> scratch, tw, tw_natural;
   std::vector<u32> acc;
@@ -48,8 +49,8 @@ struct HostWave {
   void poly_sync() const { pthread_barrier_wait(&t_->group_bars[group()]); }
   void wave_sync() const { pthread_barrier_wait(&t_->wave_bars[wave_]); }
   void team_sync() const { pthread_barrier_wait(&t_->team_bar); }
-  Elem* scratch() const { return t_->scratch.data() + ((size_t)buf_ * t_->groups + group()) * t_->n; }
-  const Elem* scratch_of(int s) const { return t_->scratch.data() + ((size_t)buf_ * t_->groups + s) * t_->n; }
+  Elem* scratch() const { return t_->scratch.data() + ((size_t)buf_ * t_->groups + group()) * t_->ns; }
+  const Elem* scratch_of(int s) const { return t_->scratch.data() + ((size_t)buf_ * t_->groups + s) * t_->ns; }
   u32* acc() const { return t_->acc.data() + (size_t)group() * t_->n; }
   const Elem* twiddles() const { return t_->tw.data(); }
   const Elem* twiddles_uniform() const { return t_->tw_natural.data(); }
@@ -66,20 +67,23 @@ void run_team(int logn, int groups, int g, const std::function<void(const HostWa
   team.g = g;
   team.exb = g_exchange_buffers;
   team.groups = groups;
-  team.scratch.resize((size_t)groups * team.n * team.exb);
+  const int lt = logn - F::kLogShrink;  // log2 of the transform size
+  team.ns = 1 << lt;
+  team.scratch.resize((size_t)groups * team.ns * team.exb);
   team.acc.resize((size_t)groups * team.n);
   // natural-order table -> the working copy's layout, as the kernels stage it into LDS
   std::vector<elem>& natural = team.tw_natural;
-  natural.resize(ntt_twiddle_words(team.n));
-  F::fill_twiddles(logn, natural.data());
+  natural.resize(ntt_twiddle_words(team.ns));
+  F::fill_twiddles(lt, natural.data());
   team.tw.resize(natural.size());
   for (int tid = 0; tid < 64; ++tid) {
-    switch (logn * 8 + g) {
+    switch (lt * 8 + g) {
       case 9 * 8 + 1: ntt_stage_twiddles<9, 1>(team.tw.data(), natural.data(), tid, 64); break;
       case 10 * 8 + 1: ntt_stage_twiddles<10, 1>(team.tw.data(), natural.data(), tid, 64); break;
       case 11 * 8 + 1: ntt_stage_twiddles<11, 1>(team.tw.data(), natural.data(), tid, 64); break;
       case 11 * 8 + 2: ntt_stage_twiddles<11, 2>(team.tw.data(), natural.data(), tid, 64); break;
       case 11 * 8 + 4: ntt_stage_twiddles<11, 4>(team.tw.data(), natural.data(), tid, 64); break;
+      case 10 * 8 + 2: ntt_stage_twiddles<10, 2>(team.tw.data(), natural.data(), tid, 64); break;  // complex transform, N = 2048
       default: std::abort();
     }
   }
@@ -99,11 +103,20 @@ void run_team(int logn, int groups, int g, const std::function<void(const HostWa
   for (auto& t : th) t.join();
 }
 
+// shapes a transform policy can run in the emulator: any for the prime fields; the complex transform holds two
+// coefficients per element, so it needs N/2 >= 512 points per G waves x 8 elements
+template <class F, int LOGN, int G>
+constexpr bool shape_ok() {
+  return F::kLogShrink == 0 || (LOGN == 10 && G == 1) || (LOGN == 11 && (G == 1 || G == 2));
+}
+
 template <class F, int LOGN, int G>
 void poly_ntt(const typename F::elem* in, typename F::elem* out, int inverse) {
   typedef typename F::elem elem;
   constexpr int E = NttShape<LOGN, G>::kE;
   constexpr int T = NttShape<LOGN, G>::kThreads;
+  if constexpr (F::kLogShrink != 0) std::abort();  // (the raw transform test is for the prime fields)
+  else
   run_team<F>(LOGN, 1, G, [&](const HostWave<elem>& w) {
     elem x[E];
     if (!inverse) {
@@ -122,11 +135,14 @@ template <class F, int LOGN, int G>
 void bsk_prepare(size_t polys, const u32* src, typename F::elem* dst) {
   typedef typename F::elem elem;
   constexpr int N = 1 << LOGN;
-  const elem n_inv = F::n_inv(LOGN);
-  run_team<F>(LOGN, 1, G, [&](const HostWave<elem>& w) {
-    for (size_t i = 0; i < polys; ++i)
-      bsk_prepare_wave<F, LOGN, G>(w, src + i * N, dst + i * N * F::kParts, n_inv);
-  });
+  if constexpr (!shape_ok<F, LOGN, G>()) std::abort();
+  else {
+    const elem n_inv = F::n_inv(LOGN - F::kLogShrink);
+    run_team<F>(LOGN, 1, G, [&](const HostWave<elem>& w) {
+      for (size_t i = 0; i < polys; ++i)
+        bsk_prepare_wave<F, LOGN, G>(w, src + i * N, dst + i * (N >> F::kLogShrink) * F::kParts, n_inv);
+    });
+  }
 }
 
 template <class F, int LOGN, int K, int G>
@@ -136,6 +152,8 @@ void blind_rotate(const PbsParams& P, size_t batch, const u32* lwe, const u32* t
   constexpr int N = 1 << LOGN;
   constexpr int E = NttShape<LOGN, G>::kE;
   constexpr int T = NttShape<LOGN, G>::kThreads;
+  if constexpr (!shape_ok<F, LOGN, G>()) std::abort();
+  else
   run_team<F>(LOGN, K + 1, G, [&](const HostWave<elem>& w) {
     for (size_t b = 0; b < batch; ++b) {
       blind_rotate_team<F, LOGN, K, G>(w, P, lwe + b * (P.n + 1), tv + b * tv_stride, bsk);
@@ -156,6 +174,8 @@ void blind_rotate_bmmp(const PbsParams& P, size_t batch, const u32* lwe, const u
   constexpr int N = 1 << LOGN;
   constexpr int E = NttShape<LOGN, G>::kE;
   constexpr int T = NttShape<LOGN, G>::kThreads;
+  if constexpr (!shape_ok<F, LOGN, G>()) std::abort();
+  else
   run_team<F>(LOGN, K + 1, G, [&](const HostWave<elem>& w) {
     for (size_t b = 0; b < batch; ++b) {
       blind_rotate_bmmp_team<F, LOGN, K, G>(w, P, lwe + b * (P.n + 1), tv + b * tv_stride, bsk);
@@ -172,6 +192,8 @@ template <class F, int LOGN, int K, int G>
 void ext_product(const PbsParams& P, const typename F::elem* ggsw, const u32* glwe, u32* out) {
   typedef typename F::elem elem;
   constexpr int N = 1 << LOGN;
+  if constexpr (!shape_ok<F, LOGN, G>()) std::abort();
+  else
   run_team<F>(LOGN, K + 1, G, [&](const HostWave<elem>& w) {
     const int p = w.group();
     auto src = [&](int j) -> u32 { return glwe[p * N + j]; };
@@ -185,7 +207,9 @@ template <class F, int LOGN, int G>
 void glwe_body(u32 k, size_t rows, const u32* glwe, const u32* sk, u32* out, int negate) {
   typedef typename F::elem elem;
   constexpr int N = 1 << LOGN;
-  const elem n_inv = F::n_inv(LOGN);
+  if constexpr (!shape_ok<F, LOGN, G>()) std::abort();
+  else {
+  const elem n_inv = F::n_inv(LOGN - F::kLogShrink);
   run_team<F>(LOGN, 1, G, [&](const HostWave<elem>& w) {
     for (size_t row = 0; row < rows; ++row) {
       const u32* masks = glwe + row * (size_t)(k + 1) * N;
@@ -194,6 +218,7 @@ void glwe_body(u32 k, size_t rows, const u32* glwe, const u32* sk, u32* out, int
       glwe_mask_dot_key<F, LOGN, G>(w, k, masks, sk, n_inv, dst);
     }
   });
+  }
 }
 
 bool g_aligned = false;  // decomposer alignment extension (tfhe_hip.h)
@@ -223,12 +248,14 @@ PbsParams make_params(u32 n, u32 k, u32 log_n, u32 log_p, u32 padding, u32 log_b
   else return 1;
 
 // field: 1 = Goldilocks, 2 = fp64 42-bit prime (double elements), 3 = Goldilocks with split key,
-// 4 = fp64 49-bit prime with the key word taken whole; 8-byte words
+// 4 = fp64 49-bit prime with the key word taken whole; 5 = complex FFT in fp64 (16-byte elements, N/2 of them
+// per polynomial); prepared keys are counted in 8-byte words for every field
 #define DISPATCH_FIELD(field, CALL)                         \
   if ((field) == 1) { typedef GlField FF; CALL }            \
   else if ((field) == 2) { typedef FpField FF; CALL }       \
   else if ((field) == 3) { typedef GlSplitField FF; CALL }  \
   else if ((field) == 4) { typedef Fp49Field FF; CALL }     \
+  else if ((field) == 5) { typedef FftField FF; CALL }      \
   else return 3;
 
 extern "C" {
@@ -236,6 +263,12 @@ extern "C" {
 void emu_set_aligned(int aligned) { g_aligned = aligned != 0; }
 void emu_set_exchange_buffers(int n) { g_exchange_buffers = n == 2 ? 2 : 1; }
 int emu_field_parts(int field) { return (field == 1 || field == 4) ? 1 : 2; }
+// 1 if the emulator can run `field` at ring degree 2^logn with g waves per polynomial
+int emu_field_shape_ok(int field, int logn, int g) {
+  if (field != 5) return 1;
+  return (logn == 10 && g == 1) || (logn == 11 && (g == 1 || g == 2));
+}
+double emu_fft_error_bound(int logn, int rows, int log_base) { return FftField::error_bound(logn, rows, log_base); }
 
 int emu_poly_ntt(int field, int logn, int g, const void* in, void* out, int inverse) {
   DISPATCH_FIELD(field, DISPATCH_LOGN(logn, g, (poly_ntt<FF, L, GG>((const FF::elem*)in, (FF::elem*)out, inverse))));

@@ -20,17 +20,30 @@ EMU_DIR = os.path.join(HERE, "emu")
 CSRC = os.path.join(ROOT, "tfhe-research_amd", "csrc")
 
 
-# Goldilocks, fp64 42-bit prime, Goldilocks with the key split in 16-bit halves, fp64 49-bit prime
-GL, FP, GLS, FP49 = 1, 2, 3, 4
-FIELDS = [GL, FP, GLS, FP49]
+# Goldilocks, fp64 42-bit prime, Goldilocks with the key split in 16-bit halves, fp64 49-bit prime,
+# complex FFT in fp64 (exact by its rounding-error bound)
+GL, FP, GLS, FP49, FFT = 1, 2, 3, 4, 5
+FIELDS = [GL, FP, GLS, FP49, FFT]
 
 
-def field_exact(field, k, logn, pbs):
+def fft_error_bound(logn, rows, log_base):
+    """field_fft.h::FftField::error_bound"""
+    import math
+    u = 2.0 ** -53
+    m, n = float(1 << (logn - 1)), float(logn - 1)
+    return 3.1 * n * 6.7 * u * rows * m * math.sqrt(m) * math.sqrt(2) * (1 << log_base) * math.sqrt(2) * 32768.0
+
+
+def field_exact(field, k, logn, pbs, g=1):
     """the bounds tfhe_context_create_with_backend checks (capi.cpp): worst-case |convolution| of
-    the (k+1)*l digit rows against the field's capacity"""
+    the (k+1)*l digit rows against the field's capacity (for the complex transform: the proven rounding
+    error of an output coefficient against 1/4, and the shapes the emulator can run it in)"""
     import math
     rows = (k + 1) * pbs[1]
     bits = math.log2(rows) + logn + pbs[0]
+    if field == FFT:
+        shape = (logn == 10 and g == 1) or (logn == 11 and g in (1, 2))
+        return shape and pbs[0] <= 16 and fft_error_bound(logn, rows, pbs[0]) < 0.25
     if field == FP:
         return bits + 15 < 40.9 and pbs[0] <= 9
     if field == FP49:
@@ -219,7 +232,7 @@ def exchange_buffers(emu, request):
 @pytest.mark.parametrize("field", FIELDS)
 @pytest.mark.parametrize("k,logn,n,pbs,log_p,g", CASES)
 def test_external_product_vs_oracle(emu, oracle, exchange_buffers, field, k, logn, n, pbs, log_p, g):
-    if not field_exact(field, k, logn, pbs):
+    if not field_exact(field, k, logn, pbs, g):
         pytest.skip("outside this field's exactness bound")
     params = oracle.Params(k, logn, n, oracle.Decomposer(*pbs), log_p=log_p)
     rng = np.random.default_rng(11 * logn + k)
@@ -243,7 +256,7 @@ def test_external_product_worst_case_magnitudes(emu, oracle, field, k, logn, pbs
     params = oracle.Params(k, logn, 1, oracle.Decomposer(*pbs))
     log_base, levels = pbs
     N = params.N
-    if not field_exact(field, k, logn, pbs):
+    if not field_exact(field, k, logn, pbs, g):
         pytest.skip("outside this field's exactness bound: the context selects another field here")
     first_shift = log_base * (32 // log_base - levels)
     # word whose every kept limb is B-1 with an incoming carry -> digits B ... (top ones), built by brute force
@@ -273,7 +286,7 @@ def test_external_product_worst_case_magnitudes(emu, oracle, field, k, logn, pbs
 @pytest.mark.parametrize("field", FIELDS)
 @pytest.mark.parametrize("k,logn,n,pbs,log_p,g", CASES)
 def test_blind_rotate_and_extract_vs_oracle(emu, oracle, exchange_buffers, field, k, logn, n, pbs, log_p, g):
-    if not field_exact(field, k, logn, pbs):
+    if not field_exact(field, k, logn, pbs, g):
         pytest.skip("outside this field's exactness bound")
     params = oracle.Params(k, logn, n, oracle.Decomposer(*pbs), log_p=log_p)
     batch = 2
@@ -341,6 +354,8 @@ def test_wide_base_needs_split_goldilocks(emu, oracle):
 @pytest.mark.parametrize("k,logn,g", [(1, 9, 1), (2, 9, 1), (1, 10, 1), (2, 11, 1), (2, 11, 2), (2, 11, 4)])
 def test_glwe_mask_dot_key_vs_oracle(emu, oracle, field, k, logn, g):
     # binary key x whole mask word: k N 2^31 against the field capacity (always inside for k <= 2)
+    if not emu.emu_field_shape_ok(field, logn, g):
+        pytest.skip("the complex transform has no kernel shape here")
     """glwe_mask_dot_key (the a*s of glwe.rs:197/:252) against the oracle's encrypt_glwe_zero /
     decrypt_glwe_ciphertext with the same pre-drawn samples; includes the all-ones key and
     all-0xFFFFFFFF / 0x8000 / 0x7FFF mask halves that maximise the convolution."""

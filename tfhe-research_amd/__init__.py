@@ -30,7 +30,7 @@ STATUS_NAMES = {
  TFHE_ERR_NO_DEVICE, TFHE_ERR_EXACTNESS, TFHE_ERR_IO) = range(1, 9)
 FILE_BSK, FILE_KSK, FILE_LWE, FILE_GLWE, FILE_GGSW, FILE_WORDS = 1, 2, 3, 4, 5, 6
 DECOMPOSER_PBS, DECOMPOSER_KS = 0, 1
-BACKEND_AUTO, BACKEND_GOLDILOCKS, BACKEND_FP64, BACKEND_GOLDILOCKS_SPLIT, BACKEND_FP64_P49 = 0, 1, 2, 3, 4
+BACKEND_AUTO, BACKEND_GOLDILOCKS, BACKEND_FP64, BACKEND_GOLDILOCKS_SPLIT, BACKEND_FP64_P49, BACKEND_FP64_FFT = 0, 1, 2, 3, 4, 5
 
 # truth[(lhs << 1) | rhs]
 GATE_AND = (0, 0, 0, 1)

@@ -266,8 +266,9 @@ double convolution_bits(const tfhe_params* p, double key_bits) {
 
 template <class F>
 hipError_t upload_twiddles(tfhe_context* ctx) {
-  std::vector<typename F::elem> tw(ntt_twiddle_words((int)ctx->N));
-  F::fill_twiddles((int)ctx->params.glwe_poly_degree, tw.data());
+  // (the complex transform has N/2 points: F::kLogShrink = 1)
+  std::vector<typename F::elem> tw(ntt_twiddle_words((int)(ctx->N >> F::kLogShrink)));
+  F::fill_twiddles((int)ctx->params.glwe_poly_degree - F::kLogShrink, tw.data());
   hipError_t e = hipMalloc(&ctx->d_tw, tw.size() * sizeof(typename F::elem));
   if (e != hipSuccess) return e;
   return hipMemcpy(ctx->d_tw, tw.data(), tw.size() * sizeof(typename F::elem), hipMemcpyHostToDevice);
@@ -335,6 +336,13 @@ int tfhe_context_create_with_backend(const tfhe_params* params, int device, int 
                        (params->glwe_dimension + 1) * params->pbs_decomposer.levels <= (uint32_t)Fp49Field::kMaxRows;
   const bool gl_ok = convolution_bits(params, GlField::key_bits()) < GlField::exact_bits();
   const bool gls_ok = convolution_bits(params, GlSplitField::key_bits()) < GlSplitField::exact_bits();
+  // the complex transform is exact while the proven rounding error of an output coefficient stays below
+  // FftField::kMaxError (field_fft.h); its kernels exist at N = 1024
+  const bool fft_ok = launch::field_shape_supported(launch::kFieldFft, params->glwe_poly_degree) &&
+                      params->pbs_decomposer.log_base <= (uint32_t)FftField::kMaxLogBase &&
+                      FftField::error_bound((int)params->glwe_poly_degree,
+                                            (int)((params->glwe_dimension + 1) * params->pbs_decomposer.levels),
+                                            (int)params->pbs_decomposer.log_base) < FftField::kMaxError;
   int field = 0;
   if (backend == TFHE_BACKEND_AUTO) {
     const char* env = std::getenv("TFHE_HIP_BACKEND");
@@ -342,6 +350,7 @@ int tfhe_context_create_with_backend(const tfhe_params* params, int device, int 
     else if (env && std::strcmp(env, "fp64") == 0) backend = TFHE_BACKEND_FP64;
     else if (env && std::strcmp(env, "fp64-p49") == 0) backend = TFHE_BACKEND_FP64_P49;
     else if (env && std::strcmp(env, "goldilocks-split") == 0) backend = TFHE_BACKEND_GOLDILOCKS_SPLIT;
+    else if (env && std::strcmp(env, "fp64-fft") == 0) backend = TFHE_BACKEND_FP64_FFT;
   }
   if (backend == TFHE_BACKEND_AUTO)
     field = fp49_ok ? launch::kFieldFp49
@@ -352,8 +361,10 @@ int tfhe_context_create_with_backend(const tfhe_params* params, int device, int 
   else if (backend == TFHE_BACKEND_FP64) field = launch::kFieldFp64;
   else if (backend == TFHE_BACKEND_GOLDILOCKS_SPLIT) field = launch::kFieldGoldilocksSplit;
   else if (backend == TFHE_BACKEND_FP64_P49) field = launch::kFieldFp49;
+  else if (backend == TFHE_BACKEND_FP64_FFT) field = launch::kFieldFft;
   else return TFHE_ERR_INVALID_ARGUMENT;
-  if ((field == launch::kFieldFp49 && !fp49_ok) || (field == launch::kFieldFp64 && !fp_ok) || (field == launch::kFieldGoldilocks && !gl_ok) ||
+  if (field == launch::kFieldFft && !launch::field_shape_supported(field, params->glwe_poly_degree)) return TFHE_ERR_UNSUPPORTED;
+  if ((field == launch::kFieldFft && !fft_ok) || (field == launch::kFieldFp49 && !fp49_ok) || (field == launch::kFieldFp64 && !fp_ok) || (field == launch::kFieldGoldilocks && !gl_ok) ||
       (field == launch::kFieldGoldilocksSplit && !gls_ok))
     return TFHE_ERR_EXACTNESS;
   int count = 0;
@@ -397,6 +408,7 @@ int tfhe_context_create_with_backend(const tfhe_params* params, int device, int 
     if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e, "hipEventCreate");
   e = field == launch::kFieldFp64   ? upload_twiddles<FpField>(ctx)
       : field == launch::kFieldFp49 ? upload_twiddles<Fp49Field>(ctx)
+      : field == launch::kFieldFft  ? upload_twiddles<FftField>(ctx)
                                     : upload_twiddles<GlField>(ctx);  // both Goldilocks fields share the table
   if (e != hipSuccess) return bail(e, "twiddle upload");
   if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->d_queue), 2 * sizeof(unsigned long long))) != hipSuccess ||
@@ -414,6 +426,7 @@ const char* tfhe_context_backend(const tfhe_context* ctx) {
   if (!ctx) return "";
   return ctx->field == launch::kFieldFp64     ? "fp64-p42"
          : ctx->field == launch::kFieldFp49   ? "fp64-p49"
+         : ctx->field == launch::kFieldFft    ? "fp64-fft"
          : ctx->field == launch::kFieldGoldilocks ? "goldilocks"
                                                   : "goldilocks-split";
 }

@@ -99,6 +99,18 @@ struct Fp49Field {
   }
   TFHE_HD static u32 finish(const elem (&parts)[kParts]) { return to_u32(reduce(parts[0])); }
 
+  // ---- hooks shared with the complex transform (field_fft.h): one ring coefficient per element here
+  static constexpr int kLogShrink = 0;
+  static constexpr int kCoeffs = 1;
+  static constexpr bool kFusedMac = false;
+  TFHE_HD static elem mul_add(elem d, elem k, elem acc) { return add(acc, mul(d, k)); }
+  TFHE_HD static elem mul_inverse(elem a, elem w) { return mul(a, w); }
+  TFHE_HD static constexpr int inverse_twiddle_index(int h, int i) { return 2 * h - 1 - i; }
+  TFHE_HD static elem from_digits(const u32 (&d)[kCoeffs]) { return from_digit(d[0]); }
+  TFHE_HD static elem from_key_words(const u32 (&w)[kCoeffs], int part) { return from_key_word(w[0], part); }
+  TFHE_HD static elem scale_key(elem x, elem n_inv) { return reduce(mul(x, n_inv)); }
+  TFHE_HD static void finish(const elem (&parts)[kParts], u32 (&out)[kCoeffs]) { out[0] = finish(parts); }
+
   // ---- host-side constants (integer arithmetic mod p) ----
   static inline u64 mulmod_u64(u64 a, u64 b) { return (u64)((unsigned __int128)a * b % P_INT); }
   static inline u64 powmod_u64(u64 b, u64 e) {

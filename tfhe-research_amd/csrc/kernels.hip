@@ -26,6 +26,20 @@ struct GroupOf {
   static constexpr int value = (LOGN >= 11) ? TFHE_GROUP_N2048 : 1;
 };
 
+// Shapes a transform policy is instantiated for.  The complex transform (field_fft.h) holds two
+// coefficients per element, so its N/2-point transform has 8 elements per lane at N = 1024 with one wave
+// per polynomial; N = 512 would leave 4 (the register passes need 8), N = 2048 over four waves as well.
+template <class F, int LOGN>
+constexpr bool field_shape_ok() {
+  return F::kLogShrink == 0 || LOGN == 10;
+}
+
+// bytes of the twiddle table of a field at ring degree 2^LOGN
+template <class F, int LOGN>
+constexpr size_t twiddle_bytes() {
+  return (size_t)ntt_twiddle_words(1 << (LOGN - F::kLogShrink)) * sizeof(typename F::elem);
+}
+
 template <class Elem, int G, int EXB = 1>
 struct DeviceWave {
   unsigned char* team_base_;  // LDS of group 0 of this team (its exchange buffer in use)
@@ -115,7 +129,8 @@ struct TeamCfg {
   static constexpr int kWaves = (K + 1) * G;
   static constexpr int kThreads = kWaves * 64;
   static constexpr unsigned kGroupLds = (unsigned)N * 8u * EXB + (unsigned)N * 4u;
-  static constexpr size_t kTwBytes = (size_t)ntt_twiddle_words(N) * 8;  // multiple of 16
+  // room for the largest table: (N + 18) 8-byte elements or (N/2 + 18) 16-byte ones
+  static constexpr size_t kTwBytes = (size_t)N * 8 + 18 * 16;  // multiple of 16
   static constexpr size_t kLds = kTwBytes + (size_t)(K + 1) * kGroupLds;
   static constexpr int kMinWavesGl = (NttShape<LOGN, G>::kE == 8) ? 3 : TFHE_WAVES_PER_SIMD_GL;
   static constexpr int kMinWavesFp = (NttShape<LOGN, G>::kE == 8) ? 3 : TFHE_WAVES_PER_SIMD_FP;
@@ -126,8 +141,9 @@ __device__ __forceinline__ DeviceWave<typename F::elem, GroupOf<LOGN>::value, Ex
 make_wave(unsigned char* smem, const typename F::elem* tw_global) {
   typedef typename F::elem elem;
   using C = TeamCfg<LOGN, K>;
+  static_assert(twiddle_bytes<F, LOGN>() <= C::kTwBytes, "twiddle table");
   elem* tw = reinterpret_cast<elem*>(smem);
-  ntt_stage_twiddles<LOGN, C::G>(tw, tw_global, (int)threadIdx.x, (int)blockDim.x);
+  ntt_stage_twiddles<LOGN - F::kLogShrink, C::G>(tw, tw_global, (int)threadIdx.x, (int)blockDim.x);
   __syncthreads();
   DeviceWave<elem, C::G, C::EXB> w;
   w.group_ = (int)(threadIdx.x / (64u * C::G));
@@ -156,7 +172,7 @@ __global__ void __launch_bounds__(256) bsk_prepare_kernel(const typename F::elem
   constexpr int N = 1 << LOGN;
   constexpr int G = GroupOf<LOGN>::value;
   elem* twl = reinterpret_cast<elem*>(g_smem);
-  ntt_stage_twiddles<LOGN, G>(twl, tw, (int)threadIdx.x, (int)blockDim.x);
+  ntt_stage_twiddles<LOGN - F::kLogShrink, G>(twl, tw, (int)threadIdx.x, (int)blockDim.x);
   __syncthreads();
   const int group = (int)(threadIdx.x / (64u * G));
   const int groups = (int)(blockDim.x / (64u * G));
@@ -174,15 +190,15 @@ __global__ void __launch_bounds__(256) bsk_prepare_kernel(const typename F::elem
   w.team_base_ = nullptr;
   w.tw_ = twl;
   w.twg_ = tw;
-  w.scratch_ = reinterpret_cast<elem*>(g_smem + (size_t)ntt_twiddle_words(N) * 8 + (size_t)group * N * 8);
+  w.scratch_ = reinterpret_cast<elem*>(g_smem + twiddle_bytes<F, LOGN>() + (size_t)group * N * 8);
   w.acc_ = nullptr;
-  bsk_prepare_wave<F, LOGN, G>(w, polys + poly * N, spectra + poly * N * F::kParts, n_inv);
+  bsk_prepare_wave<F, LOGN, G>(w, polys + poly * N, spectra + poly * (N >> F::kLogShrink) * F::kParts, n_inv);
 }
 
 // ------------------------------------------------------------------------------ blind rotation
 template <class F, int LOGN, int K>
 __global__ void __launch_bounds__((TeamCfg<LOGN, K>::kThreads),
-                                  (F::kId == FpField::kId || F::kId == Fp49Field::kId
+                                  (F::kId == FpField::kId || F::kId == Fp49Field::kId || F::kId == FftField::kId
                                        ? TeamCfg<LOGN, K>::kMinWavesFp
                                        : TeamCfg<LOGN, K>::kMinWavesGl))
 blind_rotate_kernel(PbsParams P, const typename F::elem* __restrict__ tw,
@@ -256,7 +272,7 @@ blind_rotate_bmmp_kernel(PbsParams P, const typename F::elem* __restrict__ tw,
 // out the kernel is only 4 % faster.)
 template <class F, int LOGN, int K>
 __global__ void __launch_bounds__((TeamCfg<LOGN, K>::kThreads),
-                                  (F::kId == FpField::kId || F::kId == Fp49Field::kId
+                                  (F::kId == FpField::kId || F::kId == Fp49Field::kId || F::kId == FftField::kId
                                        ? TeamCfg<LOGN, K>::kMinWavesFp
                                        : TeamCfg<LOGN, K>::kMinWavesGl))
 external_product_kernel(PbsParams P, const typename F::elem* __restrict__ tw,
@@ -543,7 +559,7 @@ __global__ void __launch_bounds__(256) glwe_body_kernel(const typename F::elem* 
   constexpr int N = 1 << LOGN;
   constexpr int G = GroupOf<LOGN>::value;
   elem* twl = reinterpret_cast<elem*>(g_smem);
-  ntt_stage_twiddles<LOGN, G>(twl, tw, (int)threadIdx.x, (int)blockDim.x);
+  ntt_stage_twiddles<LOGN - F::kLogShrink, G>(twl, tw, (int)threadIdx.x, (int)blockDim.x);
   __syncthreads();
   const int group = (int)(threadIdx.x / (64u * G));
   const int groups = (int)(blockDim.x / (64u * G));
@@ -563,7 +579,7 @@ __global__ void __launch_bounds__(256) glwe_body_kernel(const typename F::elem* 
   w.team_base_ = nullptr;
   w.tw_ = twl;
   w.twg_ = tw;
-  w.scratch_ = reinterpret_cast<elem*>(g_smem + (size_t)ntt_twiddle_words(N) * 8 + (size_t)group * N * 8);
+  w.scratch_ = reinterpret_cast<elem*>(g_smem + twiddle_bytes<F, LOGN>() + (size_t)group * N * 8);
   w.acc_ = nullptr;
   const u32* masks = rows + row * (size_t)(k + 1) * N;
   const u32* body = masks + (size_t)k * N;
@@ -663,23 +679,27 @@ template <class F, int LOGN, int K>
 hipError_t launch_blind_rotate(hipStream_t s, const PbsParams& P, const void* tw_v, const u32* lwe_in,
                                size_t batch, const u32* tv, size_t tv_stride, const void* bsk_v,
                                u32* glwe_out, u32* lwe_extracted) {
-  using C = TeamCfg<LOGN, K>;
-  auto tw = static_cast<const typename F::elem*>(tw_v);
-  auto bsk = static_cast<const typename F::elem*>(bsk_v);
-  auto kern = blind_rotate_kernel<F, LOGN, K>;
-  static std::atomic<unsigned long long> lds_done{0};
-  hipError_t e = allow_lds(kern, C::kLds, lds_done);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(C::kThreads), C::kLds, s, P, tw, lwe_in, batch,
-                     tv, tv_stride, bsk, glwe_out, lwe_extracted);
-  return hipGetLastError();
+  if constexpr (!field_shape_ok<F, LOGN>()) {
+    return hipErrorInvalidValue;  // the context never picks such a field (capi.cpp)
+  } else {
+    using C = TeamCfg<LOGN, K>;
+    auto tw = static_cast<const typename F::elem*>(tw_v);
+    auto bsk = static_cast<const typename F::elem*>(bsk_v);
+    auto kern = blind_rotate_kernel<F, LOGN, K>;
+    static std::atomic<unsigned long long> lds_done{0};
+    hipError_t e = allow_lds(kern, C::kLds, lds_done);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(C::kThreads), C::kLds, s, P, tw, lwe_in, batch,
+                       tv, tv_stride, bsk, glwe_out, lwe_extracted);
+    return hipGetLastError();
+  }
 }
 
 template <class F, int LOGN, int K>
 hipError_t launch_blind_rotate_bmmp(hipStream_t s, const PbsParams& P, const void* tw_v, const u32* lwe_in,
                                     size_t batch, const u32* tv, size_t tv_stride, const void* bsk_v,
                                     u32* glwe_out, u32* lwe_extracted) {
-  if constexpr (LOGN != 9) {
+  if constexpr (LOGN != 9 || !field_shape_ok<F, LOGN>()) {
     return hipErrorInvalidValue;  // shape_supported_bmmp() keeps callers away
   } else {
     using C = TeamCfg<LOGN, K>;
@@ -700,71 +720,84 @@ hipError_t launch_external_product(hipStream_t s, const PbsParams& P, const void
                                    const void* ggsw_v, size_t ggsw_stride_words, const u32* glwe_in,
                                    u32* ct1_inout, const u32* cmux_ct0, size_t batch, u32* glwe_out,
                                    unsigned long long* queue) {
-  using C = TeamCfg<LOGN, K>;
-  constexpr size_t kLdsWithTicket = C::kLds + 16;
-  auto tw = static_cast<const typename F::elem*>(tw_v);
-  auto ggsw = static_cast<const typename F::elem*>(ggsw_v);
-  auto kern = external_product_kernel<F, LOGN, K>;
-  static std::atomic<unsigned long long> lds_done{0};
-  hipError_t e = allow_lds(kern, kLdsWithTicket, lds_done);
-  if (e != hipSuccess) return e;
-  // persistent grid: as many teams as the device keeps resident at once (LDS or registers decide)
-  static std::atomic<int> resident{0};
-  int teams = resident.load(std::memory_order_relaxed);
-  if (teams == 0) {
-    int dev = 0, cus = 0, per_cu = 0;
-    e = hipGetDevice(&dev);
-    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (e == hipSuccess)
-      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), C::kThreads, kLdsWithTicket);
+  if constexpr (!field_shape_ok<F, LOGN>()) {
+    return hipErrorInvalidValue;
+  } else {
+    using C = TeamCfg<LOGN, K>;
+    constexpr size_t kLdsWithTicket = C::kLds + 16;
+    auto tw = static_cast<const typename F::elem*>(tw_v);
+    auto ggsw = static_cast<const typename F::elem*>(ggsw_v);
+    auto kern = external_product_kernel<F, LOGN, K>;
+    static std::atomic<unsigned long long> lds_done{0};
+    hipError_t e = allow_lds(kern, kLdsWithTicket, lds_done);
     if (e != hipSuccess) return e;
-    teams = cus * (per_cu > 0 ? per_cu : 1);
-    resident.store(teams, std::memory_order_relaxed);
+    // persistent grid: as many teams as the device keeps resident at once (LDS or registers decide)
+    static std::atomic<int> resident{0};
+    int teams = resident.load(std::memory_order_relaxed);
+    if (teams == 0) {
+      int dev = 0, cus = 0, per_cu = 0;
+      e = hipGetDevice(&dev);
+      if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      if (e == hipSuccess)
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), C::kThreads, kLdsWithTicket);
+      if (e != hipSuccess) return e;
+      teams = cus * (per_cu > 0 ? per_cu : 1);
+      resident.store(teams, std::memory_order_relaxed);
+    }
+    const size_t grid = batch < (size_t)teams ? batch : (size_t)teams;
+    // the work queue pays from 16 samples per team (see the kernel)
+    unsigned long long* use_queue = batch / grid >= 16 ? queue : nullptr;
+    if (use_queue && (e = hipMemsetAsync(use_queue, 0, sizeof(unsigned long long), s)) != hipSuccess) return e;
+    // the stride arrives in 8-byte words; the kernel counts elements
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C::kThreads), kLdsWithTicket, s, P, tw, ggsw,
+                       ggsw_stride_words / (sizeof(typename F::elem) / 8), glwe_in, ct1_inout, cmux_ct0, batch, glwe_out, use_queue);
+    return hipGetLastError();
   }
-  const size_t grid = batch < (size_t)teams ? batch : (size_t)teams;
-  // the work queue pays from 16 samples per team (see the kernel)
-  unsigned long long* use_queue = batch / grid >= 16 ? queue : nullptr;
-  if (use_queue && (e = hipMemsetAsync(use_queue, 0, sizeof(unsigned long long), s)) != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C::kThreads), kLdsWithTicket, s, P, tw, ggsw,
-                     ggsw_stride_words, glwe_in, ct1_inout, cmux_ct0, batch, glwe_out, use_queue);
-  return hipGetLastError();
 }
 
 template <class F, int LOGN>
 hipError_t launch_bsk_prepare(hipStream_t s, const void* tw_v, const u32* polys, size_t poly_count,
                               void* spectra_v) {
-  constexpr int N = 1 << LOGN;
-  constexpr int G = GroupOf<LOGN>::value;
-  constexpr int groups = 4 / G;  // polynomials per 256-thread workgroup
-  const size_t lds = (size_t)ntt_twiddle_words(N) * 8 + (size_t)N * 8 * groups;
-  auto tw = static_cast<const typename F::elem*>(tw_v);
-  auto spectra = static_cast<typename F::elem*>(spectra_v);
-  auto kern = bsk_prepare_kernel<F, LOGN>;
-  static std::atomic<unsigned long long> lds_done{0};
-  hipError_t e = allow_lds(kern, lds, lds_done);
-  if (e != hipSuccess) return e;
-  const unsigned grid = (unsigned)((poly_count + groups - 1) / groups);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, tw, polys, poly_count, spectra,
-                     F::n_inv(LOGN));
-  return hipGetLastError();
+  if constexpr (!field_shape_ok<F, LOGN>()) {
+    return hipErrorInvalidValue;
+  } else {
+    constexpr int N = 1 << LOGN;
+    constexpr int G = GroupOf<LOGN>::value;
+    constexpr int groups = 4 / G;  // polynomials per 256-thread workgroup
+    const size_t lds = twiddle_bytes<F, LOGN>() + (size_t)N * 8 * groups;
+    auto tw = static_cast<const typename F::elem*>(tw_v);
+    auto spectra = static_cast<typename F::elem*>(spectra_v);
+    auto kern = bsk_prepare_kernel<F, LOGN>;
+    static std::atomic<unsigned long long> lds_done{0};
+    hipError_t e = allow_lds(kern, lds, lds_done);
+    if (e != hipSuccess) return e;
+    const unsigned grid = (unsigned)((poly_count + groups - 1) / groups);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, tw, polys, poly_count, spectra,
+                       F::n_inv(LOGN - F::kLogShrink));
+    return hipGetLastError();
+  }
 }
 
 template <class F, int LOGN>
 hipError_t launch_glwe_body(hipStream_t s, const void* tw_v, u32 k, const u32* rows, size_t row_count,
                             const u32* sk, u32* dst, size_t dst_stride, u32 negate) {
-  constexpr int N = 1 << LOGN;
-  constexpr int G = GroupOf<LOGN>::value;
-  constexpr int groups = 4 / G;  // rows per 256-thread workgroup
-  const size_t lds = (size_t)ntt_twiddle_words(N) * 8 + (size_t)N * 8 * groups;
-  auto tw = static_cast<const typename F::elem*>(tw_v);
-  auto kern = glwe_body_kernel<F, LOGN>;
-  static std::atomic<unsigned long long> lds_done{0};
-  hipError_t e = allow_lds(kern, lds, lds_done);
-  if (e != hipSuccess) return e;
-  const unsigned grid = (unsigned)((row_count + groups - 1) / groups);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, tw, k, rows, row_count, sk, dst, dst_stride,
-                     negate, F::n_inv(LOGN));
-  return hipGetLastError();
+  if constexpr (!field_shape_ok<F, LOGN>()) {
+    return hipErrorInvalidValue;
+  } else {
+    constexpr int N = 1 << LOGN;
+    constexpr int G = GroupOf<LOGN>::value;
+    constexpr int groups = 4 / G;  // rows per 256-thread workgroup
+    const size_t lds = twiddle_bytes<F, LOGN>() + (size_t)N * 8 * groups;
+    auto tw = static_cast<const typename F::elem*>(tw_v);
+    auto kern = glwe_body_kernel<F, LOGN>;
+    static std::atomic<unsigned long long> lds_done{0};
+    hipError_t e = allow_lds(kern, lds, lds_done);
+    if (e != hipSuccess) return e;
+    const unsigned grid = (unsigned)((row_count + groups - 1) / groups);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, tw, k, rows, row_count, sk, dst, dst_stride,
+                       negate, F::n_inv(LOGN - F::kLogShrink));
+    return hipGetLastError();
+  }
 }
 
 }  // namespace
@@ -776,6 +809,8 @@ bool shape_supported(u32 log_n, u32 k) { return log_n >= 9 && log_n <= 11 && (k 
 bool shape_supported_bmmp(u32 log_n, u32 k) { return log_n == 9 && (k == 1 || k == 2); }
 
 int field_parts(int field) { return (field == kFieldGoldilocks || field == kFieldFp49) ? 1 : 2; }
+
+bool field_shape_supported(int field, u32 log_n) { return field != kFieldFft || log_n == 10; }
 
 // (field, log_n, k) -> template instantiation.  TFHE_DEV_CFG2_ONLY builds just the BASELINE cfg2
 // shape (N = 1024, k = 1) for fast iteration on the kernels.
@@ -823,10 +858,13 @@ int field_parts(int field) { return (field == kFieldGoldilocks || field == kFiel
   }
 #endif
 
-#if defined(TFHE_DEV_FIELD_FP_ONLY) || defined(TFHE_DEV_FIELD_FP49_ONLY)  // dev builds: one field (fast iteration)
+#if defined(TFHE_DEV_FIELD_FP_ONLY) || defined(TFHE_DEV_FIELD_FP49_ONLY) || defined(TFHE_DEV_FIELD_FFT_ONLY)  // dev builds: one field (fast iteration)
 #if defined(TFHE_DEV_FIELD_FP49_ONLY)
 #define TFHE_DEV_FIELD_ID kFieldFp49
 #define TFHE_DEV_FIELD_T Fp49Field
+#elif defined(TFHE_DEV_FIELD_FFT_ONLY)
+#define TFHE_DEV_FIELD_ID kFieldFft
+#define TFHE_DEV_FIELD_T FftField
 #else
 #define TFHE_DEV_FIELD_ID kFieldFp64
 #define TFHE_DEV_FIELD_T FpField
@@ -853,6 +891,9 @@ int field_parts(int field) { return (field == kFieldGoldilocks || field == kFiel
       BODY                                                                    \
     } else if ((field) == kFieldFp49) {                                       \
       typedef Fp49Field FF;                                                   \
+      BODY                                                                    \
+    } else if ((field) == kFieldFft) {                                        \
+      typedef FftField FF;                                                    \
       BODY                                                                    \
     }                                                                         \
     return hipErrorInvalidValue;                                              \

@@ -12,11 +12,14 @@ constexpr int kFieldGoldilocks = GlField::kId;  // 1
 constexpr int kFieldFp64 = FpField::kId;        // 2
 constexpr int kFieldGoldilocksSplit = GlSplitField::kId;  // 3
 constexpr int kFieldFp49 = Fp49Field::kId;                // 4
+constexpr int kFieldFft = FftField::kId;                  // 5: complex FFT in fp64, exact by a rounding bound
 
 // true if a kernel set is instantiated for (log_n, k)
 bool shape_supported(u32 log_n, u32 k);
 // spectra per key polynomial for a field (1 or 2)
 int field_parts(int field);
+// true if the field's kernels exist at this ring degree (the complex transform: N = 1024 only)
+bool field_shape_supported(int field, u32 log_n);
 
 // twiddle table psi_rev[N] (8-byte field elements) must already be on the device;
 // spectra: poly_count x field_parts x N elements

@@ -152,9 +152,17 @@ template <class F, int LOGN, int K, int G, int KEYS, class Ctx, class Src, class
 TFHE_HD void external_product_team_keys(const Ctx& c, const PbsParams& P, const typename F::elem* ggsw,
                                         size_t ggsw_words, Src src, Out out, EndKey end_of_key) {
   typedef typename F::elem elem;
-  constexpr int E = NttShape<LOGN, G>::kE;
+  // LT: log2 of the transform size -- the ring degree in the prime fields, half of it for the complex
+  // transform, whose elements hold the coefficient pairs (j, j + N/2) (field_fft.h).  A lane holds E
+  // transform elements and EC = E * F::kCoeffs ring coefficients per array; element r of a lane pairs the
+  // coefficients r and r + E of its coefficient array (indices (r + q E) T + lane).
+  constexpr int LT = LOGN - F::kLogShrink;
+  constexpr int E = NttShape<LT, G>::kE;
+  constexpr int EC = NttShape<LOGN, G>::kE;
+  constexpr int CO = F::kCoeffs;
+  static_assert(EC == E * CO, "coefficients per lane");
   constexpr int T = NttShape<LOGN, G>::kThreads;  // threads per polynomial
-  constexpr int N = 1 << LOGN;
+  constexpr int N = 1 << LT;                       // transform elements per polynomial
   constexpr int PARTS = F::kParts;
   const int lane = c.tid();   // thread index inside my polynomial's group of G waves
   const int me = c.group();   // polynomial / output column owned by my group
@@ -180,11 +188,11 @@ TFHE_HD void external_product_team_keys(const Ctx& c, const PbsParams& P, const 
   // The lane-uniform constants of the forward transforms' top window (wave_ntt.h::TopConsts) are fetched
   // while the operand is read and rounded, stay in scalar registers for all levels, and make room for
   // the inverse transforms' block after the last level.
-  TopConsts<F, LOGN, G, true> ftop;
+  TopConsts<F, LT, G, true> ftop;
   if constexpr (TFHE_TOP_PREFETCH) ftop.issue(c.twiddles_uniform());
-  u32 v[E];
+  u32 v[EC];
 #pragma unroll
-  for (int r = 0; r < E; ++r) v[r] = round_value(src(r * T + lane), P.ignored_bits);
+  for (int r = 0; r < EC; ++r) v[r] = round_value(src(r * T + lane), P.ignored_bits);
   if constexpr (TFHE_TOP_PREFETCH) ftop.ready();
 
   // Key tiles of one level for my column: idx = s * PARTS + q, s = source polynomial 0..K, q = part.
@@ -197,7 +205,8 @@ TFHE_HD void external_product_team_keys(const Ctx& c, const PbsParams& P, const 
 #define TFHE_CHUNK 8
 #endif
   constexpr int TILES = (K + 1) * ACCS;
-  constexpr int CH = E < TFHE_CHUNK ? E : TFHE_CHUNK;
+  constexpr int CH_MAX = TFHE_CHUNK * 8 / (int)sizeof(elem);  // TFHE_CHUNK counts 8-byte registers
+  constexpr int CH = E < CH_MAX ? E : CH_MAX;
   constexpr int CHUNKS = TILES * (E / CH);
   // tile of source polynomial s and accumulator a = (key m, part q)
   auto tile_ptr = [&](u32 level, int s, int a) -> const elem* {
@@ -222,7 +231,7 @@ TFHE_HD void external_product_team_keys(const Ctx& c, const PbsParams& P, const 
     {
       const elem* tile = tile_ptr(level, 0, 0);
 #pragma unroll
-      for (int r = 0; r < CH; ++r) kbuf[0][r] = tile[spectrum_slot<LOGN, G>(lane, r)];
+      for (int r = 0; r < CH; ++r) kbuf[0][r] = tile[spectrum_slot<LT, G, (int)sizeof(elem)>(lane, r)];
     }
     c.compiler_fence();
     {
@@ -232,18 +241,28 @@ TFHE_HD void external_product_team_keys(const Ctx& c, const PbsParams& P, const 
       // Goldilocks fields reach bases above 2^23 (one-level decompositions) and branch at run time
       if (F::kMaxLogBase <= 23 || P.log_base <= 23) {
 #pragma unroll
-        for (int r = 0; r < E; ++r) work[r] = F::from_digit(decompose_limb_fast<true>(v[r], shift, P.log_base, carry_width));
+        for (int r = 0; r < E; ++r) {
+          u32 dg[CO];
+#pragma unroll
+          for (int q = 0; q < CO; ++q) dg[q] = decompose_limb_fast<true>(v[r + q * E], shift, P.log_base, carry_width);
+          work[r] = F::from_digits(dg);
+        }
       } else {
 #pragma unroll
-        for (int r = 0; r < E; ++r) work[r] = F::from_digit(decompose_limb_fast<false>(v[r], shift, P.log_base, carry_width));
+        for (int r = 0; r < E; ++r) {
+          u32 dg[CO];
+#pragma unroll
+          for (int q = 0; q < CO; ++q) dg[q] = decompose_limb_fast<false>(v[r + q * E], shift, P.log_base, carry_width);
+          work[r] = F::from_digits(dg);
+        }
       }
       // digits are tiny (|d| <= B <= 2^F::kSmallBits, enforced when the context picks the field):
       // the first butterfly stage uses F::mul_small.  A team barrier precedes every level (the
       // caller's for level 0, the previous level's below) and nobody reads this buffer after it.
       if constexpr (TFHE_TOP_PREFETCH)
-        ntt_forward<F, LOGN, G, true, true>(cl, work, ftop);
+        ntt_forward<F, LT, G, true, true>(cl, work, ftop);
       else
-        ntt_forward<F, LOGN, G, true, true>(cl, work);
+        ntt_forward<F, LT, G, true, true>(cl, work);
       if (F::kReduceSpectrum) {  // little lazy headroom: MAC terms must start from |d| <= p/2
 #pragma unroll
         for (int r = 0; r < E; ++r) work[r] = F::reduce(work[r]);
@@ -252,7 +271,7 @@ TFHE_HD void external_product_team_keys(const Ctx& c, const PbsParams& P, const 
       // the buffer (wave_ntt.h), conflict-free 8-byte accesses
       elem* mine = cl.scratch();
 #pragma unroll
-      for (int r = 0; r < E; ++r) mine[exchange_slot<LOGN, G>(lane, r)] = work[r];
+      for (int r = 0; r < E; ++r) mine[exchange_slot<LT, G>(lane, r)] = work[r];
     }
     c.team_sync();
     // chunk order: source polynomial s, then the CH-register piece of its spectrum, then the
@@ -268,12 +287,12 @@ TFHE_HD void external_product_team_keys(const Ctx& c, const PbsParams& P, const 
         constexpr int nq = (ci + 1) % ACCS, nr0 = (((ci + 1) / ACCS) % PIECES) * CH, ns = (ci + 1) / (ACCS * PIECES);
         const elem* tile = tile_ptr(level, ns, nq);
 #pragma unroll
-        for (int r = 0; r < CH; ++r) kbuf[nxt][r] = tile[spectrum_slot<LOGN, G>(lane, nr0 + r)];
+        for (int r = 0; r < CH; ++r) kbuf[nxt][r] = tile[spectrum_slot<LT, G, (int)sizeof(elem)>(lane, nr0 + r)];
       }
       if constexpr (q == 0) {
         const elem* spec = cl.scratch_of(s);
 #pragma unroll
-        for (int r = 0; r < CH; ++r) d[r] = spec[exchange_slot<LOGN, G>(lane, r0 + r)];
+        for (int r = 0; r < CH; ++r) d[r] = spec[exchange_slot<LT, G>(lane, r0 + r)];
       }
       c.compiler_fence();  // keep the next chunk's loads above this chunk's arithmetic
 #pragma unroll
@@ -281,14 +300,14 @@ TFHE_HD void external_product_team_keys(const Ctx& c, const PbsParams& P, const 
         if (SPLIT)
           F::mac(d[r], kbuf[cur][r], accum[q][r0 + r], accum_lo[SPLIT ? q : 0][SPLIT ? r0 + r : 0]);
         else
-          accum[q][r0 + r] = F::add(accum[q][r0 + r], F::mul(d[r], kbuf[cur][r]));
+          accum[q][r0 + r] = F::mul_add(d[r], kbuf[cur][r], accum[q][r0 + r]);
       }
     });
     if (!two) c.team_sync();  // everyone is done reading before the next transform reuses the buffer
   }
 
   const Ctx ci = c.with_exchange_buffer(two ? (int)(P.levels & 1u) : 0);
-  TopConsts<F, LOGN, G, false> itop;  // arrives during the first two passes of the first inverse transform
+  TopConsts<F, LT, G, false> itop;  // arrives during the first two passes of the first inverse transform
   if constexpr (TFHE_TOP_PREFETCH) itop.issue(c.twiddles_uniform());
   static_for<0, KEYS>([&](auto key_c) {
     constexpr int m = decltype(key_c)::value;
@@ -300,17 +319,20 @@ TFHE_HD void external_product_team_keys(const Ctx& c, const PbsParams& P, const 
                             : F::before_inverse(accum[q][r]);
       if constexpr (TFHE_TOP_PREFETCH) {
         if constexpr (q == 0) itop.ready();  // nothing else is in flight here: the wait is for the block alone
-        ntt_inverse<F, LOGN, G>(ci, accum[q], itop);
+        ntt_inverse<F, LT, G>(ci, accum[q], itop);
       }
       else
-        ntt_inverse<F, LOGN, G>(ci, accum[q]);
+        ntt_inverse<F, LT, G>(ci, accum[q]);
     });
 #pragma unroll
     for (int r = 0; r < E; ++r) {
       elem parts[PARTS];
 #pragma unroll
       for (int q = 0; q < PARTS; ++q) parts[q] = accum[m * PARTS + q][r];
-      out(m, r * T + lane, F::finish(parts));
+      u32 vals[CO];
+      F::finish(parts, vals);
+#pragma unroll
+      for (int q = 0; q < CO; ++q) out(m, (r + q * E) * T + lane, vals[q]);
     }
     end_of_key(m);
   });
@@ -363,7 +385,7 @@ TFHE_HD void blind_rotate_team(const Ctx& c, const PbsParams& P, const u32* lwe 
     c.poly_sync();
   }
 
-  const size_t ggsw_words = (size_t)(K + 1) * P.levels * (K + 1) * F::kParts * N;
+  const size_t ggsw_words = (size_t)(K + 1) * P.levels * (K + 1) * F::kParts * (N >> F::kLogShrink);  // elements
 #pragma unroll 1
   for (u32 i = 0; i < P.n; ++i) {
     const u32 a_tilde = c.uniform(switch_modulus_2n(lwe[i], LOGN));
@@ -422,7 +444,7 @@ TFHE_HD void blind_rotate_bmmp_team(const Ctx& c, const PbsParams& P, const u32*
     }
     c.poly_sync();
   }
-  const size_t ggsw_words = (size_t)(K + 1) * P.levels * (K + 1) * F::kParts * N;
+  const size_t ggsw_words = (size_t)(K + 1) * P.levels * (K + 1) * F::kParts * (N >> F::kLogShrink);  // elements
   u32* stage = reinterpret_cast<u32*>(c.scratch());  // N u32 of my group's transpose buffer
 #pragma unroll 1
   for (u32 pair = 0; pair < P.n / 2; ++pair) {
@@ -470,22 +492,28 @@ TFHE_HD void sample_extract_team(const Ctx& c, u32* out /* K*N + 1 */) {
 // Forward NTT of one u32 polynomial of the bootstrapping key into the prepared layout,
 // pre-scaled by N^-1.
 template <class F, int LOGN, int G, class Ctx>
-TFHE_HD void bsk_prepare_wave(const Ctx& c, const u32* poly, typename F::elem* spec /* [kParts][N] */,
+TFHE_HD void bsk_prepare_wave(const Ctx& c, const u32* poly, typename F::elem* spec /* [kParts][N >> kLogShrink] */,
                               typename F::elem n_inv) {
   typedef typename F::elem elem;
-  constexpr int E = NttShape<LOGN, G>::kE;
+  constexpr int LT = LOGN - F::kLogShrink;
+  constexpr int E = NttShape<LT, G>::kE;
+  constexpr int CO = F::kCoeffs;
   constexpr int T = NttShape<LOGN, G>::kThreads;
-  constexpr int N = 1 << LOGN;
+  constexpr int NS = 1 << LT;
   const int lane = c.tid();
 #pragma unroll 1
   for (int part = 0; part < F::kParts; ++part) {
     elem x[E];
 #pragma unroll
-    for (int r = 0; r < E; ++r) x[r] = F::from_key_word(poly[r * T + lane], part);
-    ntt_forward<F, LOGN, G>(c, x);
+    for (int r = 0; r < E; ++r) {
+      u32 w[CO];
 #pragma unroll
-    for (int r = 0; r < E; ++r)
-      spec[(size_t)part * N + spectrum_slot<LOGN, G>(lane, r)] = F::reduce(F::mul(x[r], n_inv));
+      for (int q = 0; q < CO; ++q) w[q] = poly[(r + q * E) * T + lane];
+      x[r] = F::from_key_words(w, part);
+    }
+    ntt_forward<F, LT, G>(c, x);
+#pragma unroll
+    for (int r = 0; r < E; ++r) spec[(size_t)part * NS + spectrum_slot<LT, G, (int)sizeof(elem)>(lane, r)] = F::scale_key(x[r], n_inv);
   }
 }
 
@@ -501,7 +529,9 @@ template <class F, int LOGN, int G, class Ctx, class Out>
 TFHE_HD void glwe_mask_dot_key(const Ctx& c, u32 k, const u32* masks /* [k][N] */,
                                const u32* sk /* [k][N] */, typename F::elem n_inv, Out out) {
   typedef typename F::elem elem;
-  constexpr int E = NttShape<LOGN, G>::kE;
+  constexpr int LT = LOGN - F::kLogShrink;
+  constexpr int E = NttShape<LT, G>::kE;
+  constexpr int CO = F::kCoeffs;
   constexpr int T = NttShape<LOGN, G>::kThreads;
   constexpr int N = 1 << LOGN;
   constexpr int PARTS = F::kParts;
@@ -517,19 +547,29 @@ TFHE_HD void glwe_mask_dot_key(const Ctx& c, u32 k, const u32* masks /* [k][N] *
   for (u32 i = 0; i < k; ++i) {
     elem s[E];
 #pragma unroll
-    for (int r = 0; r < E; ++r) s[r] = F::from_digit(sk[(size_t)i * N + r * T + lane]);
-    ntt_forward<F, LOGN, G, true>(c, s);
+    for (int r = 0; r < E; ++r) {
+      u32 w[CO];
 #pragma unroll
-    for (int r = 0; r < E; ++r) s[r] = F::reduce(F::mul(s[r], n_inv));
+      for (int q = 0; q < CO; ++q) w[q] = sk[(size_t)i * N + (r + q * E) * T + lane];
+      s[r] = F::from_digits(w);
+    }
+    ntt_forward<F, LT, G, true>(c, s);
+#pragma unroll
+    for (int r = 0; r < E; ++r) s[r] = F::scale_key(s[r], n_inv);
     static_for<0, PARTS>([&](auto part_c) {
       constexpr int q = decltype(part_c)::value;
       elem x[E];
 #pragma unroll
-      for (int r = 0; r < E; ++r) x[r] = F::from_key_word(masks[(size_t)i * N + r * T + lane], q);
-      ntt_forward<F, LOGN, G>(c, x);
+      for (int r = 0; r < E; ++r) {
+        u32 w[CO];
+#pragma unroll
+        for (int qq = 0; qq < CO; ++qq) w[qq] = masks[(size_t)i * N + (r + qq * E) * T + lane];
+        x[r] = F::from_key_words(w, q);
+      }
+      ntt_forward<F, LT, G>(c, x);
 #pragma unroll
       for (int r = 0; r < E; ++r)
-        accum[q][r] = F::add(accum[q][r], F::mul(F::kReduceSpectrum ? F::reduce(x[r]) : x[r], s[r]));
+        accum[q][r] = F::mul_add(F::kReduceSpectrum ? F::reduce(x[r]) : x[r], s[r], accum[q][r]);
     });
   }
 
@@ -537,14 +577,17 @@ TFHE_HD void glwe_mask_dot_key(const Ctx& c, u32 k, const u32* masks /* [k][N] *
     constexpr int q = decltype(part_c)::value;
 #pragma unroll
     for (int r = 0; r < E; ++r) accum[q][r] = F::before_inverse(accum[q][r]);
-    ntt_inverse<F, LOGN, G>(c, accum[q]);
+    ntt_inverse<F, LT, G>(c, accum[q]);
   });
 #pragma unroll
   for (int r = 0; r < E; ++r) {
     elem parts[PARTS];
 #pragma unroll
     for (int q = 0; q < PARTS; ++q) parts[q] = accum[q][r];
-    out(r * T + lane, F::finish(parts));
+    u32 vals[CO];
+    F::finish(parts, vals);
+#pragma unroll
+    for (int q = 0; q < CO; ++q) out((r + q * E) * T + lane, vals[q]);
   }
 }
 

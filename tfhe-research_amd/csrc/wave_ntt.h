@@ -37,6 +37,7 @@
 // and, for the team code in pbs_wave.h, int exchange_buffers() const (1 or 2 LDS buffers per group)
 // and Ctx with_exchange_buffer(int i) const (a copy whose scratch()/scratch_of() use buffer i).
 #pragma once
+#include "field_fft.h"
 #include "field_fp.h"
 #include "field_fp49.h"
 #include "field_gl.h"
@@ -175,6 +176,16 @@ TFHE_HD void uniform_wait() {
 #endif
 }
 
+// 8-byte word type an element is made of (one word, or re/im for the complex transform)
+template <class Elem>
+struct WordOf {
+  typedef Elem type;
+};
+template <>
+struct WordOf<cplx> {
+  typedef double type;
+};
+
 // the top window's constants read straight from the table (the compiler places the loads)
 template <class Elem>
 struct TopFromTable {
@@ -187,26 +198,34 @@ struct TopFromTable {
 // ... prefetched.  FORWARD_SMALL: the forward transform of gadget digits, whose first two or three
 // stages are fused in fields with kFuseFirstTwo (constants at [N ..]); otherwise plain stages only
 // (any inverse transform; forward transforms of fields without fused stages).  Plain stage s of the
-// window reads psi_rev[2^s .. 2^(s+1)), s < e = log2(E).
+// window reads table elements [2^s, 2^(s+1)), s < e = log2(E).  The blocks are counted in 8-byte WORDS
+// (an element is one word, or two for the complex transform): words [0, 4), [4, 8), [8, 16), ...
 template <class F, int LOGN, int G, bool FORWARD_SMALL>
 struct TopConsts {
   typedef typename F::elem elem;
+  typedef typename WordOf<elem>::type word;
+  static constexpr int W = (int)(sizeof(elem) / sizeof(word));  // words per element
   static constexpr int E = NttShape<LOGN, G>::kE;
   static constexpr int e = NttShape<LOGN, G>::kEBits;
   static constexpr int N = 1 << LOGN;
   static constexpr bool FUSE = FORWARD_SMALL && F::kFuseFirstTwo && e >= 2;
   static constexpr bool FUSE3 = TFHE_RADIX8 && FUSE && e >= 3;
+  static_assert(!FUSE || W == 1, "fused stages: one-word elements");
   static constexpr int kFirstPlain = FUSE3 ? 8 : FUSE ? 4 : 1;  // lowest table index a plain stage reads
-  UniformBlock<elem, 4> lo;       // [0, 4): psi_rev[1..3]
-  UniformBlock<elem, 4> mid;      // [4, 8)
-  UniformBlock<elem, 8> hi[3];    // [8, 16), [16, 24), [24, 32)
-  UniformBlock<elem, 8> fa, fb;   // [N, N+8), [N+8, N+16)
-  UniformBlock<elem, 2> fc;       // [N+16, N+18)   (FUSE without the radix-8 step: fc holds [N, N+2))
-  TFHE_HD void issue(const elem* table) {
+  static constexpr int kWords = E * W;                          // the window reads words [W, kWords)
+  static_assert(kWords <= 32, "at most 32 words of top-window twiddles");
+  UniformBlock<word, 4> lo;       // words [0, 4)
+  UniformBlock<word, 4> mid;      // [4, 8)
+  UniformBlock<word, 8> hi[3];    // [8, 16), [16, 24), [24, 32)
+  UniformBlock<word, 8> fa, fb;   // fused-stage constants [N, N+8), [N+8, N+16)
+  UniformBlock<word, 2> fc;       // [N+16, N+18)   (FUSE without the radix-8 step: fc holds [N, N+2))
+  static constexpr bool kMid = kWords > 4 && kFirstPlain * W < 8;
+  TFHE_HD void issue(const elem* table_e) {
+    const word* table = reinterpret_cast<const word*>(table_e);
     lo.template issue<0>(table);
-    if constexpr (E > 4 && kFirstPlain < 8) mid.template issue<4>(table);
-    if constexpr (E > 8) hi[0].template issue<8>(table);
-    if constexpr (E > 16) {
+    if constexpr (kMid) mid.template issue<4>(table);
+    if constexpr (kWords > 8) hi[0].template issue<8>(table);
+    if constexpr (kWords > 16) {
       hi[1].template issue<16>(table);
       hi[2].template issue<24>(table);
     }
@@ -222,9 +241,9 @@ struct TopConsts {
   TFHE_HD void ready() {
     uniform_wait();
     lo.pin();
-    if constexpr (E > 4 && kFirstPlain < 8) mid.pin();
-    if constexpr (E > 8) hi[0].pin();
-    if constexpr (E > 16) {
+    if constexpr (kMid) mid.pin();
+    if constexpr (kWords > 8) hi[0].pin();
+    if constexpr (kWords > 16) {
       hi[1].pin();
       hi[2].pin();
     }
@@ -234,10 +253,21 @@ struct TopConsts {
     }
     if constexpr (FUSE) fc.pin();
   }
-  TFHE_HD elem tw(int i) const { return i < 4 ? lo[i] : i < 8 ? mid[i - 4] : hi[(i - 8) >> 3][(i - 8) & 7]; }
+  TFHE_HD word at(int w) const { return w < 4 ? lo[w] : w < 8 ? mid[w - 4] : hi[(w - 8) >> 3][(w - 8) & 7]; }
+  TFHE_HD elem tw(int i) const {
+    if constexpr (W == 1) {
+      return at(i);
+    } else {
+      return elem{at(2 * i), at(2 * i + 1)};
+    }
+  }
   TFHE_HD elem fused(int i) const {
-    if constexpr (FUSE3) return i < 8 ? fa[i] : i < 16 ? fb[i - 8] : fc[i - 16];
-    return fc[i];
+    if constexpr (W == 1) {
+      if constexpr (FUSE3) return i < 8 ? fa[i] : i < 16 ? fb[i - 8] : fc[i - 16];
+      return fc[i];
+    } else {
+      return F::zero();
+    }
   }
 };
 
@@ -267,8 +297,11 @@ TFHE_HD int ntt_index(int tid, int r) {
 // memory position (in elements) of spectrum register r of thread `tid` inside one NTT-domain
 // polynomial of the prepared bootstrapping key: pairs of registers are interleaved so that one
 // global_load_dwordx4 per lane reads 64 x 16 B = 1 KiB contiguous per wave.
-template <int LOGN, int G>
+// (16-byte elements -- the complex transform -- are one global_load_dwordx4 each: register r of all
+// threads is contiguous)
+template <int LOGN, int G, int ELEM_BYTES = 8>
 TFHE_HD int spectrum_slot(int tid, int r) {
+  if (ELEM_BYTES == 16) return r * NttShape<LOGN, G>::kThreads + tid;
   return (r >> 1) * (2 * NttShape<LOGN, G>::kThreads) + tid * 2 + (r & 1);
 }
 
@@ -404,13 +437,15 @@ TFHE_HD void ntt_pass_inverse(const Ctx& c, typename F::elem (&x)[NttShape<LOGN,
     for (int r0 = 0; r0 < E; ++r0) {
       if ((r0 >> rb) & 1) continue;
       const int r1 = r0 | (1 << rb);
-      const elem w = TOP ? top.tw(2 * h - 1 - (r0 >> (rb + 1)))
+      // (F::inverse_twiddle_index(h, i) = 2h - 1 - i in the prime fields, h + i for the complex transform,
+      // whose mul_inverse conjugates the entry)
+      const elem w = TOP ? top.tw(F::inverse_twiddle_index(h, r0 >> (rb + 1)))
                      : TFHE_TW_TRANSPOSED ? tw[h + (cnt - 1 - (r0 >> (rb + 1))) * H + (H - 1 - hi)]
-                                          : tw[2 * h - 1 - (hi << (LO + e - b - 1)) - (r0 >> (rb + 1))];
+                                          : tw[F::inverse_twiddle_index(h, (hi << (LO + e - b - 1)) + (r0 >> (rb + 1)))];
       const elem u = x[r0];
       const elem v = x[r1];
       x[r0] = F::add(u, v);
-      x[r1] = F::mul(F::sub(v, u), w);
+      x[r1] = F::mul_inverse(F::sub(v, u), w);
     }
     // fields with little lazy headroom (F::kInverseSweepEvery > 0): the un-multiplied leg doubles
     // per stage, so everything is brought back to |.| <= p/2 after every kInverseSweepEvery-th stage
