@@ -242,7 +242,7 @@ def main():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0,
                     help="time budget of the single-thread CPU leg (it stops after CPU_BASELINE_PBS bootstraps anyway)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", default="auto", choices=["auto", "goldilocks", "fp64", "goldilocks-split", "fp64-p49"])
+    ap.add_argument("--backend", default="auto", choices=["auto", "goldilocks", "fp64", "goldilocks-split", "fp64-p49", "fp64-fft"])
     ap.add_argument("--kernel", default="bootstrap", choices=["bootstrap", "external_product"],
                     help="external_product: time the standalone GGSW x GLWE kernel (ggsw.rs:132-161) instead of the PBS")
     ap.add_argument("--ggsw-per-sample", action="store_true",
@@ -320,7 +320,8 @@ def main():
         ksk = rand_words(*params.ksk_shape())
 
     backend = {"auto": pkg.BACKEND_AUTO, "goldilocks": pkg.BACKEND_GOLDILOCKS, "fp64": pkg.BACKEND_FP64,
-               "goldilocks-split": pkg.BACKEND_GOLDILOCKS_SPLIT, "fp64-p49": pkg.BACKEND_FP64_P49}[args.backend]
+               "goldilocks-split": pkg.BACKEND_GOLDILOCKS_SPLIT, "fp64-p49": pkg.BACKEND_FP64_P49,
+               "fp64-fft": pkg.BACKEND_FP64_FFT}[args.backend]
     if args.kernel == "external_product":
         return bench_external_product(args, pkg, params, batch, dev, rand_words, world, rank, local_rank, backend)
     ctx = pkg.Context(params, device=local_rank, backend=backend)
@@ -397,7 +398,9 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f64" if backend_name.startswith("fp64") else "u64",
-        "dtype_note": ("exact NTT over the 49-bit prime 671317819555841 in fp64" if backend_name == "fp64-p49"
+        "dtype_note": ("complex FFT in fp64, exact by a proven rounding-error bound (csrc/field_fft.h); same bits as the exact-NTT backends"
+                       if backend_name == "fp64-fft"
+                       else "exact NTT over the 49-bit prime 671317819555841 in fp64" if backend_name == "fp64-p49"
                        else "exact NTT over the 42-bit prime 2^42-24575 in fp64" if backend_name.startswith("fp64")
                        else "exact NTT over the Goldilocks prime in u64") + "; ciphertext words are wrapping u32",
         "data": "synthetic",

@@ -84,8 +84,8 @@ int tfhe_params_validate(const tfhe_params *params);
  *   GOLDILOCKS p = 2^64 - 2^32 + 1, u64 arithmetic; needs (k+1)*l * N * B * 2^32 < 2^62
  *   GOLDILOCKS_SPLIT  the same field with the key split into 16-bit halves; needs
  *              (k+1)*l * N * B * 2^15 < 2^62, which every base the reference can express satisfies
- *   AUTO       the first of FP64_P49, FP64, GOLDILOCKS, GOLDILOCKS_SPLIT whose bound holds (env
- *              TFHE_HIP_BACKEND=fp64-p49|fp64|goldilocks|goldilocks-split overrides AUTO). */
+ *   AUTO       the first of FP64_FFT (below), FP64_P49, FP64, GOLDILOCKS, GOLDILOCKS_SPLIT whose bound holds
+ *              (env TFHE_HIP_BACKEND=fp64-fft|fp64-p49|fp64|goldilocks|goldilocks-split overrides AUTO). */
 #define TFHE_BACKEND_AUTO 0
 #define TFHE_BACKEND_GOLDILOCKS 1
 #define TFHE_BACKEND_FP64 2

@@ -11,7 +11,7 @@ from gpu_common import pkg
 pytestmark = pytest.mark.gpu
 
 SETS = ["ref_test", "misaligned"]
-BACKENDS = ["auto", "fp64", "fp64-p49", "goldilocks", "goldilocks-split"]
+BACKENDS = ["auto", "fp64", "fp64-p49", "fp64-fft", "goldilocks", "goldilocks-split"]
 
 
 def pkg_params(p):
@@ -23,7 +23,8 @@ def pkg_params(p):
 def backend_id(name):
     m = pkg()
     return {"fp64": m.BACKEND_FP64, "goldilocks": m.BACKEND_GOLDILOCKS, "auto": m.BACKEND_AUTO,
-            "goldilocks-split": m.BACKEND_GOLDILOCKS_SPLIT, "fp64-p49": m.BACKEND_FP64_P49}[name]
+            "goldilocks-split": m.BACKEND_GOLDILOCKS_SPLIT, "fp64-p49": m.BACKEND_FP64_P49,
+            "fp64-fft": m.BACKEND_FP64_FFT}[name]
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
@@ -38,6 +39,8 @@ def test_hip_path_reproduces_the_golden_trace(name, backend):
     except m.TfheError as e:
         if e.status == m.TFHE_ERR_EXACTNESS:
             pytest.skip("set outside this field's exactness bound")
+        if e.status == m.TFHE_ERR_UNSUPPORTED and backend == "fp64-fft":
+            pytest.skip("the complex-FFT backend has kernels at N = 1024 only")
         raise
     with ctx:
         ctx.load_bootstrapping_key(a["bsk"], a["ksk"])

@@ -16,13 +16,13 @@ SHAPES = [
     ("cfg5_small", 2, 11, 2, (8, 4), (4, 5), 4),   # two waves per polynomial
     ("k1_n2048", 1, 11, 3, (16, 2), (2, 9), 2),
 ]
-BACKENDS = ["auto", "goldilocks", "goldilocks-split", "fp64"]
+BACKENDS = ["auto", "goldilocks", "goldilocks-split", "fp64", "fp64-fft"]
 
 
 def backend_id(name):
     m = pkg()
     return {"auto": m.BACKEND_AUTO, "goldilocks": m.BACKEND_GOLDILOCKS, "fp64": m.BACKEND_FP64,
-            "goldilocks-split": m.BACKEND_GOLDILOCKS_SPLIT}[name]
+            "goldilocks-split": m.BACKEND_GOLDILOCKS_SPLIT, "fp64-fft": m.BACKEND_FP64_FFT}[name]
 
 
 def noise_u32(rng, std_dev, shape):
@@ -49,6 +49,8 @@ def test_encryption_entry_points_match_oracle(oracle, shape, backend):
     p = oracle.Params(k, logn, n, oracle.Decomposer(*pbs), oracle.Decomposer(*ks), log_p=log_p)
     if backend == "fp64" and not (np.log2(p.R) + logn + pbs[0] + 15 < 40.9 and pbs[0] <= 9):
         pytest.skip("outside the fp64 backend's exactness bound")  # "auto" is the 49-bit field at ref_test
+    if backend == "fp64-fft" and logn != 10:
+        pytest.skip("the complex-FFT backend has kernels at N = 1024 only")
     rng = np.random.default_rng(1000 * logn + 10 * k + n)
     glwe_sk = rng.integers(0, 2, size=(k, p.N)).astype(np.uint32)
     lwe_sk = rng.integers(0, 2, size=n).astype(np.uint32)

@@ -27,14 +27,14 @@ SHAPES = [
     ("p49_n2048", 2, 11, (2, 5)),
     ("wide_base", 1, 9, (16, 2)),
 ]
-BACKENDS = ["fp64", "fp64-p49", "goldilocks", "goldilocks-split"]
+BACKENDS = ["fp64", "fp64-p49", "fp64-fft", "goldilocks", "goldilocks-split"]
 KEY_WORDS = [0x7FFF7FFF, 0x80008000, 0x7FFF8000, 0xFFFFFFFF, 0x80000000, 0x7FFFFFFF]
 
 
 def backend_id(name):
     m = pkg()
     return {"fp64": m.BACKEND_FP64, "goldilocks": m.BACKEND_GOLDILOCKS, "goldilocks-split": m.BACKEND_GOLDILOCKS_SPLIT,
-            "fp64-p49": m.BACKEND_FP64_P49}[name]
+            "fp64-p49": m.BACKEND_FP64_P49, "fp64-fft": m.BACKEND_FP64_FFT}[name]
 
 
 def extreme_words(oracle, pbs):
@@ -57,6 +57,8 @@ def open_context(oracle, k, logn, pbs, backend, n=1):
     except m.TfheError as e:
         if e.status == m.TFHE_ERR_EXACTNESS:
             pytest.skip("outside this field's exactness bound: tfhe_context_create refuses it")
+        if e.status == m.TFHE_ERR_UNSUPPORTED and backend == "fp64-fft":
+            pytest.skip("the complex-FFT backend has kernels at N = 1024 only")
         raise
 
 

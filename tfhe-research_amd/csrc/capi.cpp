@@ -278,7 +278,7 @@ hipError_t upload_twiddles(tfhe_context* ctx) {
 
 extern "C" {
 
-const char* tfhe_version(void) { return "tfhe-research_amd 0.3 (gfx950; exact NTT backends: fp64-p49, fp64-p42, goldilocks, goldilocks-split)"; }
+const char* tfhe_version(void) { return "tfhe-research_amd 0.3 (gfx950; exact backends: fp64-fft, fp64-p49, fp64-p42, goldilocks, goldilocks-split)"; }
 
 const char* tfhe_status_string(int status) {
   switch (status) {
@@ -353,7 +353,8 @@ int tfhe_context_create_with_backend(const tfhe_params* params, int device, int 
     else if (env && std::strcmp(env, "fp64-fft") == 0) backend = TFHE_BACKEND_FP64_FFT;
   }
   if (backend == TFHE_BACKEND_AUTO)
-    field = fp49_ok ? launch::kFieldFp49
+    field = fft_ok  ? launch::kFieldFft
+            : fp49_ok ? launch::kFieldFp49
             : fp_ok ? launch::kFieldFp64
             : gl_ok ? launch::kFieldGoldilocks
                     : launch::kFieldGoldilocksSplit;
