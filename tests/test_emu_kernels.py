@@ -31,7 +31,7 @@ def fft_error_bound(logn, rows, log_base):
     import math
     u = 2.0 ** -53
     m, n = float(1 << (logn - 1)), float(logn - 1)
-    return 3.1 * n * 6.7 * u * rows * m * math.sqrt(m) * math.sqrt(2) * (1 << log_base) * math.sqrt(2) * 32768.0
+    return 3.1 * n * 7.1 * u * rows * m * math.sqrt(m) * math.sqrt(2) * (1 << log_base) * math.sqrt(2) * 32768.0
 
 
 def field_exact(field, k, logn, pbs, g=1):

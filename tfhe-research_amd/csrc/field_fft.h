@@ -18,7 +18,8 @@
 // rint(z~_j) = z_j.  Bound on e (Higham, Accuracy and Stability of Numerical Algorithms, 2nd ed., Thm 24.2:
 // a radix-2 FFT of n stages computed with twiddles of absolute error <= mu satisfies
 // ||X~ - X||_2 <= n eta / (1 - n eta) ||X||_2, eta = mu + gamma_4 (sqrt 2 + mu), gamma_4 = 4u / (1 - 4u),
-// u = 2^-53; our twiddles are correctly rounded from long double, mu <= u, so eta <= 6.7 u = 7.4e-16; FMA
+// u = 2^-53; our twiddles are correctly rounded from long double, each component within u/2, |error| <= u / sqrt 2,
+// so eta <= 7.1 u = 7.9e-16 with room to spare; FMA
 // butterflies only tighten it).  With x the folded digits (|x_j| <= sqrt 2 B), y the folded key half
 // (|y_j| <= sqrt 2 2^15), X, Y their unnormalised transforms (||X||_2 <= M |x|max, ||Y||_inf <= M |y|max),
 // R = (k+1) l rows accumulated in the transform domain, n = log2 M stages:
@@ -27,8 +28,8 @@
 //   inverse (x 1/M, exact power of two): ||z~ - z||_2 <= ||P~ - P||_2 / sqrt M + n eta ||z||_2,
 //                    ||z||_2 <= sqrt M R M |x| |y|
 //   ==> max_j |e_j| <= ||z~ - z||_2 <= 3.1 n eta R M^1.5 |x|max |y|max =: fft_error_bound().
-// cfg2 (N=1024, k=1, l=3, B=2^7): 0.011; N=2048, k=2, l=4, B=2^8: 0.16; the reference's default
-// (N=512, k=2, l=6, B=2^4): 0.0015.  The context admits this backend only below kMaxError = 1/4; measured
+// cfg2 (N=1024, k=1, l=3, B=2^7): 0.012; N=2048, k=2, l=4, B=2^8: 0.17; the reference's default
+// (N=512, k=2, l=6, B=2^4): 0.0016.  The context admits this backend only below kMaxError = 1/4; measured
 // errors are five orders of magnitude smaller (random data: 5e-7 at cfg2), and the worst-case-magnitude
 // tests (emulator and GPU) drive every digit to +B / -B/2 and every key word to 0x80008000 / 0x7FFF7FFF.
 // The 32-bit key word is split into signed 16-bit halves like in field_fp.h (two spectra per key
@@ -135,7 +136,7 @@ struct FftField {
   static inline elem n_inv(int logm) { return elem{1.0 / (double)(1 << logm), 0.0}; }
   // worst-case |error| of one output coefficient before rounding (header comment); log_n = ring degree
   static inline double error_bound(int log_n, int rows, int log_base) {
-    const double u = 1.1102230246251565e-16, eta = 6.7 * u;
+    const double u = 1.1102230246251565e-16, eta = 7.1 * u;
     const double m = (double)(1 << (log_n - 1)), n = (double)(log_n - 1);
     const double x = 1.4142135623730951 * (double)(1u << log_base), y = 1.4142135623730951 * 32768.0;
     return 3.1 * n * eta * (double)rows * m * sqrt(m) * x * y;

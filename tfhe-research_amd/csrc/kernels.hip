@@ -21,14 +21,18 @@ namespace {
 #endif
 // (N = 1024 over two waves was measured too: 97.9 ms against 64.0 ms per cfg2 batch -- a fourth
 // register pass and cross-wave barriers cost more than the third wave per SIMD gives.)
-template <int LOGN>
+template <class F, int LOGN>
 struct GroupOf {
-  static constexpr int value = (LOGN >= 11) ? TFHE_GROUP_N2048 : 1;
+  // the complex transform has N/2 elements of 16 bytes: two waves per polynomial at N = 2048 hold 8 of
+  // them per lane and array (the register footprint of one wave at N = 1024)
+  static constexpr int value = (LOGN >= 11) ? (F::kLogShrink ? 2 : TFHE_GROUP_N2048) : 1;
 };
 
 // Shapes a transform policy is instantiated for.  The complex transform (field_fft.h) holds two
 // coefficients per element, so its N/2-point transform has 8 elements per lane at N = 1024 with one wave
-// per polynomial; N = 512 would leave 4 (the register passes need 8), N = 2048 over four waves as well.
+// per polynomial; N = 512 would leave 4 (the register passes need 8); N = 2048 over two waves (8 elements per lane again) is
+// bit-exact but leaves one 6-wave team per CU and measured 137 ms against the 42-bit field's 77 ms per 1024
+// cfg5 bootstraps (profiles/r02_kernel_ab.txt), so it is not instantiated.
 template <class F, int LOGN>
 constexpr bool field_shape_ok() {
   return F::kLogShrink == 0 || LOGN == 10;
@@ -121,10 +125,10 @@ struct ExchangeBuffersOf {
   static constexpr int value = (LOGN >= 11) ? 2 : 1;
 };
 
-template <int LOGN, int K>
+template <class F, int LOGN, int K>
 struct TeamCfg {
   static constexpr int N = 1 << LOGN;
-  static constexpr int G = GroupOf<LOGN>::value;
+  static constexpr int G = GroupOf<F, LOGN>::value;
   static constexpr int EXB = ExchangeBuffersOf<LOGN>::value;
   static constexpr int kWaves = (K + 1) * G;
   static constexpr int kThreads = kWaves * 64;
@@ -137,10 +141,10 @@ struct TeamCfg {
 };
 
 template <class F, int LOGN, int K>
-__device__ __forceinline__ DeviceWave<typename F::elem, GroupOf<LOGN>::value, ExchangeBuffersOf<LOGN>::value>
+__device__ __forceinline__ DeviceWave<typename F::elem, GroupOf<F, LOGN>::value, ExchangeBuffersOf<LOGN>::value>
 make_wave(unsigned char* smem, const typename F::elem* tw_global) {
   typedef typename F::elem elem;
-  using C = TeamCfg<LOGN, K>;
+  using C = TeamCfg<F, LOGN, K>;
   static_assert(twiddle_bytes<F, LOGN>() <= C::kTwBytes, "twiddle table");
   elem* tw = reinterpret_cast<elem*>(smem);
   ntt_stage_twiddles<LOGN - F::kLogShrink, C::G>(tw, tw_global, (int)threadIdx.x, (int)blockDim.x);
@@ -170,7 +174,7 @@ __global__ void __launch_bounds__(256) bsk_prepare_kernel(const typename F::elem
                                                          typename F::elem n_inv) {
   typedef typename F::elem elem;
   constexpr int N = 1 << LOGN;
-  constexpr int G = GroupOf<LOGN>::value;
+  constexpr int G = GroupOf<F, LOGN>::value;
   elem* twl = reinterpret_cast<elem*>(g_smem);
   ntt_stage_twiddles<LOGN - F::kLogShrink, G>(twl, tw, (int)threadIdx.x, (int)blockDim.x);
   __syncthreads();
@@ -197,15 +201,15 @@ __global__ void __launch_bounds__(256) bsk_prepare_kernel(const typename F::elem
 
 // ------------------------------------------------------------------------------ blind rotation
 template <class F, int LOGN, int K>
-__global__ void __launch_bounds__((TeamCfg<LOGN, K>::kThreads),
+__global__ void __launch_bounds__((TeamCfg<F, LOGN, K>::kThreads),
                                   (F::kId == FpField::kId || F::kId == Fp49Field::kId || F::kId == FftField::kId
-                                       ? TeamCfg<LOGN, K>::kMinWavesFp
-                                       : TeamCfg<LOGN, K>::kMinWavesGl))
+                                       ? TeamCfg<F, LOGN, K>::kMinWavesFp
+                                       : TeamCfg<F, LOGN, K>::kMinWavesGl))
 blind_rotate_kernel(PbsParams P, const typename F::elem* __restrict__ tw,
                     const u32* __restrict__ lwe_in, size_t batch, const u32* __restrict__ tv,
                     size_t tv_stride, const typename F::elem* __restrict__ bsk,
                     u32* __restrict__ glwe_out, u32* __restrict__ lwe_extracted) {
-  using C = TeamCfg<LOGN, K>;
+  using C = TeamCfg<F, LOGN, K>;
   constexpr int N = C::N;
   constexpr int G = C::G;
   constexpr int E = NttShape<LOGN, G>::kE;
@@ -230,12 +234,12 @@ blind_rotate_kernel(PbsParams P, const typename F::elem* __restrict__ tw,
 #define TFHE_BMMP_MIN_WAVES 3
 #endif
 template <class F, int LOGN, int K>
-__global__ void __launch_bounds__((TeamCfg<LOGN, K>::kThreads), TFHE_BMMP_MIN_WAVES)
+__global__ void __launch_bounds__((TeamCfg<F, LOGN, K>::kThreads), TFHE_BMMP_MIN_WAVES)
 blind_rotate_bmmp_kernel(PbsParams P, const typename F::elem* __restrict__ tw,
                          const u32* __restrict__ lwe_in, size_t batch, const u32* __restrict__ tv,
                          size_t tv_stride, const typename F::elem* __restrict__ bsk,
                          u32* __restrict__ glwe_out, u32* __restrict__ lwe_extracted) {
-  using C = TeamCfg<LOGN, K>;
+  using C = TeamCfg<F, LOGN, K>;
   constexpr int N = C::N;
   constexpr int G = C::G;
   constexpr int E = NttShape<LOGN, G>::kE;
@@ -271,15 +275,15 @@ blind_rotate_bmmp_kernel(PbsParams P, const typename F::elem* __restrict__ tw,
 // the teams out of phase left the time per product unchanged within 2 %; with loads and stores compiled
 // out the kernel is only 4 % faster.)
 template <class F, int LOGN, int K>
-__global__ void __launch_bounds__((TeamCfg<LOGN, K>::kThreads),
+__global__ void __launch_bounds__((TeamCfg<F, LOGN, K>::kThreads),
                                   (F::kId == FpField::kId || F::kId == Fp49Field::kId || F::kId == FftField::kId
-                                       ? TeamCfg<LOGN, K>::kMinWavesFp
-                                       : TeamCfg<LOGN, K>::kMinWavesGl))
+                                       ? TeamCfg<F, LOGN, K>::kMinWavesFp
+                                       : TeamCfg<F, LOGN, K>::kMinWavesGl))
 external_product_kernel(PbsParams P, const typename F::elem* __restrict__ tw,
                         const typename F::elem* __restrict__ ggsw, size_t ggsw_stride_words,
                         const u32* glwe_in, u32* ct1_inout, const u32* cmux_ct0, size_t batch,
                         u32* glwe_out, unsigned long long* queue /* null: by stride */) {
-  using C = TeamCfg<LOGN, K>;
+  using C = TeamCfg<F, LOGN, K>;
   constexpr int N = C::N;
   constexpr int G = C::G;
   auto w = make_wave<F, LOGN, K>(g_smem, tw);
@@ -557,7 +561,7 @@ __global__ void __launch_bounds__(256) glwe_body_kernel(const typename F::elem* 
                                                        typename F::elem n_inv) {
   typedef typename F::elem elem;
   constexpr int N = 1 << LOGN;
-  constexpr int G = GroupOf<LOGN>::value;
+  constexpr int G = GroupOf<F, LOGN>::value;
   elem* twl = reinterpret_cast<elem*>(g_smem);
   ntt_stage_twiddles<LOGN - F::kLogShrink, G>(twl, tw, (int)threadIdx.x, (int)blockDim.x);
   __syncthreads();
@@ -682,7 +686,7 @@ hipError_t launch_blind_rotate(hipStream_t s, const PbsParams& P, const void* tw
   if constexpr (!field_shape_ok<F, LOGN>()) {
     return hipErrorInvalidValue;  // the context never picks such a field (capi.cpp)
   } else {
-    using C = TeamCfg<LOGN, K>;
+    using C = TeamCfg<F, LOGN, K>;
     auto tw = static_cast<const typename F::elem*>(tw_v);
     auto bsk = static_cast<const typename F::elem*>(bsk_v);
     auto kern = blind_rotate_kernel<F, LOGN, K>;
@@ -702,7 +706,7 @@ hipError_t launch_blind_rotate_bmmp(hipStream_t s, const PbsParams& P, const voi
   if constexpr (LOGN != 9 || !field_shape_ok<F, LOGN>()) {
     return hipErrorInvalidValue;  // shape_supported_bmmp() keeps callers away
   } else {
-    using C = TeamCfg<LOGN, K>;
+    using C = TeamCfg<F, LOGN, K>;
     auto tw = static_cast<const typename F::elem*>(tw_v);
     auto bsk = static_cast<const typename F::elem*>(bsk_v);
     auto kern = blind_rotate_bmmp_kernel<F, LOGN, K>;
@@ -723,7 +727,7 @@ hipError_t launch_external_product(hipStream_t s, const PbsParams& P, const void
   if constexpr (!field_shape_ok<F, LOGN>()) {
     return hipErrorInvalidValue;
   } else {
-    using C = TeamCfg<LOGN, K>;
+    using C = TeamCfg<F, LOGN, K>;
     constexpr size_t kLdsWithTicket = C::kLds + 16;
     auto tw = static_cast<const typename F::elem*>(tw_v);
     auto ggsw = static_cast<const typename F::elem*>(ggsw_v);
@@ -762,7 +766,7 @@ hipError_t launch_bsk_prepare(hipStream_t s, const void* tw_v, const u32* polys,
     return hipErrorInvalidValue;
   } else {
     constexpr int N = 1 << LOGN;
-    constexpr int G = GroupOf<LOGN>::value;
+    constexpr int G = GroupOf<F, LOGN>::value;
     constexpr int groups = 4 / G;  // polynomials per 256-thread workgroup
     const size_t lds = twiddle_bytes<F, LOGN>() + (size_t)N * 8 * groups;
     auto tw = static_cast<const typename F::elem*>(tw_v);
@@ -785,7 +789,7 @@ hipError_t launch_glwe_body(hipStream_t s, const void* tw_v, u32 k, const u32* r
     return hipErrorInvalidValue;
   } else {
     constexpr int N = 1 << LOGN;
-    constexpr int G = GroupOf<LOGN>::value;
+    constexpr int G = GroupOf<F, LOGN>::value;
     constexpr int groups = 4 / G;  // rows per 256-thread workgroup
     const size_t lds = twiddle_bytes<F, LOGN>() + (size_t)N * 8 * groups;
     auto tw = static_cast<const typename F::elem*>(tw_v);
