@@ -6,6 +6,7 @@
 // team meets at a workgroup barrier once or twice per gadget level (two or one LDS exchange
 // buffers per group) to hand the digit spectra around.
 #include <atomic>
+#include <cstdlib>
 
 #include "launch.h"
 
@@ -125,6 +126,10 @@ struct ExchangeBuffersOf {
   static constexpr int value = (LOGN >= 11) ? 2 : 1;
 };
 
+// (Two and four teams per workgroup -- one barrier sequence, one twiddle table, the second wave that asks for
+// a key tile finding it in the CU's vector L1 -- were measured for the complex transform, whose kernel draws
+// 13 TB/s of key from L2: 41.5 and 46.4 ms against 37.1 ms with one team per workgroup.  Teams that are free
+// to drift fill each other's stalls; coupling them costs more than the L1 hits give.)
 template <class F, int LOGN, int K>
 struct TeamCfg {
   static constexpr int N = 1 << LOGN;
@@ -679,6 +684,16 @@ hipError_t allow_lds(Kern kern, size_t bytes, std::atomic<unsigned long long>& d
   return e;
 }
 
+// samples per blind-rotation launch (TFHE_BR_CHUNK overrides the default for experiments)
+inline size_t blind_rotate_chunk() {
+  static const size_t chunk = [] {
+    const char* env = std::getenv("TFHE_BR_CHUNK");
+    const long v = env ? std::atol(env) : 0;
+    return v > 0 ? (size_t)v : (size_t)4096;
+  }();
+  return chunk;
+}
+
 template <class F, int LOGN, int K>
 hipError_t launch_blind_rotate(hipStream_t s, const PbsParams& P, const void* tw_v, const u32* lwe_in,
                                size_t batch, const u32* tv, size_t tv_stride, const void* bsk_v,
@@ -693,9 +708,23 @@ hipError_t launch_blind_rotate(hipStream_t s, const PbsParams& P, const void* tw
     static std::atomic<unsigned long long> lds_done{0};
     hipError_t e = allow_lds(kern, C::kLds, lds_done);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(C::kThreads), C::kLds, s, P, tw, lwe_in, batch,
-                       tv, tv_stride, bsk, glwe_out, lwe_extracted);
-    return hipGetLastError();
+    // Long batches go out in launches of blind_rotate_chunk() samples.  All teams of a launch walk the key in
+    // step (GGSW_i is read by every team at about the same time and stays hot in the L2s); in ONE launch of
+    // 131,072 samples the dispatcher refills finished teams one by one, after a few thousand samples every
+    // iteration of the key is in use somewhere and the 124 MB key streams from the Infinity Cache instead:
+    // the complex-FFT kernel, which needs 13 TB/s of key, ran 75.0 k PBS/s that way against 108.9 k at 4,096
+    // (profiles/r02_f_*).  Launches on one stream run back to back.
+    const size_t chunk = blind_rotate_chunk();
+    for (size_t off = 0; off < batch; off += chunk) {
+      const size_t here = batch - off < chunk ? batch - off : chunk;
+      hipLaunchKernelGGL(kern, dim3((unsigned)here), dim3(C::kThreads), C::kLds, s, P, tw,
+                         lwe_in + off * ((size_t)P.n + 1), here, tv + off * tv_stride, tv_stride, bsk,
+                         glwe_out ? glwe_out + off * (size_t)(K + 1) * C::N : nullptr,
+                         lwe_extracted ? lwe_extracted + off * ((size_t)K * C::N + 1) : nullptr);
+      e = hipGetLastError();
+      if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
   }
 }
 

@@ -220,7 +220,20 @@ TFHE_HD void external_product_team_keys(const Ctx& c, const PbsParams& P, const 
   // barrier per level, plus one at the end of the product (the first level of the next product
   // writes buffer 0 again).  The inverse transforms run in buffer levels & 1 under the same rule.
   const bool two = c.exchange_buffers() == 2;
-  elem kbuf[2][CH];
+#ifndef TFHE_KEY_BUFFERS
+#define TFHE_KEY_BUFFERS 2
+#endif
+  constexpr int NB = TFHE_KEY_BUFFERS;  // staging buffers: chunk i + NB - 1 is fetched while chunk i is consumed
+  elem kbuf[NB][CH];
+  // piece of the key a chunk index names: tile (source polynomial, accumulator) and offset inside it
+  auto load_chunk = [&](u32 level, auto ci_c, int buf) {
+    constexpr int ci = decltype(ci_c)::value;
+    constexpr int PIECES = E / CH;
+    constexpr int q = ci % ACCS, r0 = ((ci / ACCS) % PIECES) * CH, src_poly = ci / (ACCS * PIECES);
+    const elem* tile = tile_ptr(level, src_poly, q);
+#pragma unroll
+    for (int r = 0; r < CH; ++r) kbuf[buf][r] = tile[spectrum_slot<LT, G, (int)sizeof(elem)>(lane, r0 + r)];
+  };
   // (not unrolled: with the level count fixed at 3 and the loop fully unrolled the kernel issues 2.8 %
   // fewer instructions from 3x the code and runs no faster, profiles/r02_kernel_ab.txt)
 #pragma unroll 1
@@ -228,11 +241,7 @@ TFHE_HD void external_product_team_keys(const Ctx& c, const PbsParams& P, const 
     const u32 level = P.levels - 1 - t;
     const u32 shift = P.first_shift + P.log_base * t;
     const Ctx cl = c.with_exchange_buffer(two ? (int)(t & 1u) : 0);
-    {
-      const elem* tile = tile_ptr(level, 0, 0);
-#pragma unroll
-      for (int r = 0; r < CH; ++r) kbuf[0][r] = tile[spectrum_slot<LT, G, (int)sizeof(elem)>(lane, r)];
-    }
+    static_for<0, (NB - 1 < CHUNKS ? NB - 1 : CHUNKS)>([&](auto pre_c) { load_chunk(level, pre_c, decltype(pre_c)::value); });
     c.compiler_fence();
     {
       elem work[E];
@@ -282,13 +291,8 @@ TFHE_HD void external_product_team_keys(const Ctx& c, const PbsParams& P, const 
       constexpr int ci = decltype(ci_c)::value;
       constexpr int PIECES = E / CH;
       constexpr int q = ci % ACCS, r0 = ((ci / ACCS) % PIECES) * CH, s = ci / (ACCS * PIECES);
-      constexpr int cur = ci & 1, nxt = cur ^ 1;
-      if constexpr (ci + 1 < CHUNKS) {
-        constexpr int nq = (ci + 1) % ACCS, nr0 = (((ci + 1) / ACCS) % PIECES) * CH, ns = (ci + 1) / (ACCS * PIECES);
-        const elem* tile = tile_ptr(level, ns, nq);
-#pragma unroll
-        for (int r = 0; r < CH; ++r) kbuf[nxt][r] = tile[spectrum_slot<LT, G, (int)sizeof(elem)>(lane, nr0 + r)];
-      }
+      constexpr int cur = ci % NB;
+      if constexpr (ci + NB - 1 < CHUNKS) load_chunk(level, IntC<ci + NB - 1>{}, (ci + NB - 1) % NB);
       if constexpr (q == 0) {
         const elem* spec = cl.scratch_of(s);
 #pragma unroll

@@ -92,10 +92,18 @@ TFHE_HD int ntt_stage_window_lo(int b) {
 #ifndef TFHE_RADIX8
 #define TFHE_RADIX8 1
 #endif
-template <int LOGN, int G>
+// (the transposed layout costs the 8-byte fields their ds_read_b128 of two adjacent twiddles and measured 6 %
+// SLOWER there, so they keep table order; the complex transform's 16-byte entries are one ds_read_b128 either
+// way and it gains 1.2 % -- a third of its LDS-active cycles were conflict cycles: profiles/r02_kernel_ab.txt)
+template <int ELEM_BYTES>
+constexpr bool ntt_twiddles_transposed() {
+  return TFHE_TW_TRANSPOSED || ELEM_BYTES == 16;
+}
+
+template <int LOGN, int G, bool TRANSPOSED = (TFHE_TW_TRANSPOSED != 0)>
 TFHE_HD int ntt_twiddle_slot(int idx) {
   using S = NttShape<LOGN, G>;
-  if (!TFHE_TW_TRANSPOSED || idx <= 0 || idx >= S::kN) return idx;
+  if (!TRANSPOSED || idx <= 0 || idx >= S::kN) return idx;
   const int fl = 31 - __builtin_clz((unsigned)idx);  // m = 2^fl
   const int b = LOGN - 1 - fl;
   const int lo = ntt_stage_window_lo<LOGN, G>(b);
@@ -124,7 +132,7 @@ TFHE_HD void ntt_stage_twiddles(Elem* dst, const Elem* src, int tid, int nthread
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int i = base + u * nthreads;
-      if (i < W) dst[ntt_twiddle_slot<LOGN, G>(i)] = tmp[u];
+      if (i < W) dst[ntt_twiddle_slot<LOGN, G, ntt_twiddles_transposed<(int)sizeof(Elem)>()>(i)] = tmp[u];
     }
   }
 }
@@ -406,7 +414,7 @@ TFHE_HD void ntt_pass_forward(const Ctx& c, typename F::elem (&x)[NttShape<LOGN,
       if ((r0 >> rb) & 1) continue;
       const int r1 = r0 | (1 << rb);
       const elem w = TOP ? top.tw(m + (r0 >> (rb + 1)))
-                     : TFHE_TW_TRANSPOSED ? tw[m + (r0 >> (rb + 1)) * H + hi]
+                     : ntt_twiddles_transposed<(int)sizeof(elem)>() ? tw[m + (r0 >> (rb + 1)) * H + hi]
                                           : tw[m + (hi << (LO + e - b - 1)) + (r0 >> (rb + 1))];
       const elem u = x[r0];
       const elem v = (SMALL_FIRST && b == BHI) ? F::mul_small(x[r1], w) : F::mul(x[r1], w);
@@ -440,7 +448,8 @@ TFHE_HD void ntt_pass_inverse(const Ctx& c, typename F::elem (&x)[NttShape<LOGN,
       // (F::inverse_twiddle_index(h, i) = 2h - 1 - i in the prime fields, h + i for the complex transform,
       // whose mul_inverse conjugates the entry)
       const elem w = TOP ? top.tw(F::inverse_twiddle_index(h, r0 >> (rb + 1)))
-                     : TFHE_TW_TRANSPOSED ? tw[h + (cnt - 1 - (r0 >> (rb + 1))) * H + (H - 1 - hi)]
+                     : ntt_twiddles_transposed<(int)sizeof(elem)>() ? (F::kLogShrink ? tw[h + (r0 >> (rb + 1)) * H + hi]  // node h + hi cnt + i
+                                                           : tw[h + (cnt - 1 - (r0 >> (rb + 1))) * H + (H - 1 - hi)])
                                           : tw[F::inverse_twiddle_index(h, (hi << (LO + e - b - 1)) + (r0 >> (rb + 1)))];
       const elem u = x[r0];
       const elem v = x[r1];

@@ -5,6 +5,7 @@ set -u
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/final; mkdir -p $O
 python bench.py > $O/bench_cfg2.json.log 2>$O/bench_cfg2.err && tail -c 400 $O/bench_cfg2.json.log && \
+python bench.py --backend fp64 --no-cpu-baseline > $O/bench_cfg2_fp64_p42.json.log 2>&1 && \
 python bench.py --workload cfg4 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_cfg4.json.log 2>&1 && \
 python bench.py --workload cfg3 --gate nand --batch 65536 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_cfg3_nand.json.log 2>&1 && \
 python bench.py --workload cfg3 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_cfg3.json.log 2>&1 && \

@@ -3,6 +3,8 @@ tools/profile_pmc.sh leaves under gpurun_out/<tag>/ and prints the summary commi
 profiles/ (plus, with --json, the traffic figure bench.py reports in roofline.traffic).
     python tools/pmc_summarize.py gpurun_out/final/pmc "cfg2 batch 4096" 4096 630 65536 [--json profiles/pmc_traffic.json]
         [--kernel external_product] [--source profiles/<the file this output is committed as>]
+        [--bench-kernel 'blind_rotate_kernel<fp64-fft,10,1>'] [--mix fma,mul,add,rndne,cvt,int]  (instruction mix per wave
+        and iteration from tools/isa_report.py, for the issue floor; default: the 42-bit field's cfg2 kernel)
 (for the standalone external-product kernel pass n = 1: one product per sample and launch)
 """
 import csv
@@ -18,7 +20,9 @@ source = sys.argv[sys.argv.index("--source") + 1] if "--source" in sys.argv else
 # v_rndne_f64 4.34, 32-bit integer ops ~4.4) weighted with the shipped kernel's mix
 # (profiles/r02_d_isa_blind_rotate_loops.txt: per wave and iteration 1200 fma, 1140 mul, 1472 add, 584 rndne,
 # 48 cvt, 643 integer)
-FLOOR = (1200 * 4.78 + 1140 * 4.48 + 1472 * 4.48 + 584 * 4.34 + 48 * 4.8 + 643 * 4.4) / 5087
+MIX = [int(x) for x in (sys.argv[sys.argv.index("--mix") + 1] if "--mix" in sys.argv else "1200,1140,1472,584,48,643").split(",")]
+FLOOR = (MIX[0] * 4.78 + MIX[1] * 4.48 + MIX[2] * 4.48 + MIX[3] * 4.34 + MIX[4] * 4.8 + MIX[5] * 4.4) / sum(MIX)
+BENCH_KERNEL = sys.argv[sys.argv.index("--bench-kernel") + 1] if "--bench-kernel" in sys.argv else "blind_rotate_kernel<fp64-p42,10,1>"
 tot = defaultdict(float)
 launches = defaultdict(set)
 kernel = None
@@ -62,9 +66,10 @@ if "--json" in sys.argv and "FETCH_SIZE" in per and "WRITE_SIZE" in per:
                 "issue_floor_cycles_per_inst": FLOOR,
                 "valu_issue_frac": min(1.0, FLOOR / cpi),
                 "floor_source": "per-instruction issue rates at 2 waves per SIMD (profiles/r02_valu_issue_rates_gfx950.txt) "
-                                "weighted with the shipped kernel's instruction mix (profiles/r02_*_isa_blind_rotate_loops.txt)"}
+                                "weighted with the shipped kernel's instruction mix (profiles/r02_*_isa_blind_rotate_loops.txt): "
+                                + ",".join(str(x) for x in MIX) + " fma,mul,add,rndne,cvt,integer per wave and iteration"}
     # bench.py matches on "workload" == "<name> batch <batch>": keep it to exactly that
-    json.dump({"kernel": "blind_rotate_kernel<fp64-p42,10,1>", "workload": label.split(",")[0], "valu": valu,
+    json.dump({"kernel": BENCH_KERNEL, "workload": label.split(",")[0], "valu": valu,
                "fetch_size_kib": per["FETCH_SIZE"], "write_size_kib": per["WRITE_SIZE"],
                "traffic_bytes_per_launch": traffic,
                "note": "L2 fabric-side requests (Infinity-Cache hits included); varies with the drift of the teams inside an XCD",
