@@ -84,7 +84,8 @@ int tfhe_params_validate(const tfhe_params *params);
  *   GOLDILOCKS p = 2^64 - 2^32 + 1, u64 arithmetic; needs (k+1)*l * N * B * 2^32 < 2^62
  *   GOLDILOCKS_SPLIT  the same field with the key split into 16-bit halves; needs
  *              (k+1)*l * N * B * 2^15 < 2^62, which every base the reference can express satisfies
- *   AUTO       the first of FP64_FFT (below), FP64_P49, FP64, GOLDILOCKS, GOLDILOCKS_SPLIT whose bound holds
+ *   AUTO       the first of FP64_FFT (below; not at N = 512 where FP64_P49 is exact), FP64_P49, FP64, GOLDILOCKS,
+ *              GOLDILOCKS_SPLIT whose bound holds
  *              (env TFHE_HIP_BACKEND=fp64-fft|fp64-p49|fp64|goldilocks|goldilocks-split overrides AUTO). */
 #define TFHE_BACKEND_AUTO 0
 #define TFHE_BACKEND_GOLDILOCKS 1
@@ -94,7 +95,7 @@ int tfhe_params_validate(const tfhe_params *params);
 /* FP64_FFT: the negacyclic product through a complex FFT in fp64 (N/2 points, two coefficients per element,
  *            key split into 16-bit halves), exact by a proven bound on the rounding error of every output
  *            coefficient (csrc/field_fft.h: 3.1 n eta R M^1.5 |x| |y| < 1/4, e.g. 0.011 at N = 1024, k = 1,
- *            l = 3, log_base = 7); kernels at N = 1024.  Same bits as the exact-NTT fields. */
+ *            l = 3, log_base = 7); kernels at N = 512 and 1024.  Same bits as the exact-NTT fields. */
 #define TFHE_BACKEND_FP64_FFT 5
 
 /* Creates a context bound to HIP device `device`.  Fails with TFHE_ERR_NO_DEVICE when no GPU is

@@ -40,7 +40,7 @@ def test_hip_path_reproduces_the_golden_trace(name, backend):
         if e.status == m.TFHE_ERR_EXACTNESS:
             pytest.skip("set outside this field's exactness bound")
         if e.status == m.TFHE_ERR_UNSUPPORTED and backend == "fp64-fft":
-            pytest.skip("the complex-FFT backend has kernels at N = 1024 only")
+            pytest.skip("the complex-FFT backend has kernels at N = 512 and 1024")
         raise
     with ctx:
         ctx.load_bootstrapping_key(a["bsk"], a["ksk"])

@@ -65,7 +65,7 @@ def contexts(oracle):
             try:
                 ctx = pkg().Context(to_pkg_params(p), backend=backend_id(backend))
             except pkg().TfheError as e:
-                # the complex-FFT backend: kernels at N = 1024 only, admitted below its rounding-error bound
+                # the complex-FFT backend: kernels at N = 512 and 1024, admitted below its rounding-error bound
                 if backend == "fp64-fft" and e.status in (pkg().TFHE_ERR_UNSUPPORTED, pkg().TFHE_ERR_EXACTNESS):
                     pytest.skip("the fp64-fft backend does not cover this shape")
                 raise
@@ -246,8 +246,8 @@ def test_backend_selection(oracle):
     m = pkg()
     with m.Context(to_pkg_params(oracle.CFG2)) as ctx:  # N = 1024, rounding-error bound 0.011 < 1/4
         assert ctx.backend == "fp64-fft"
-    with pytest.raises(m.TfheError) as e:   # the complex transform's kernels exist at N = 1024
-        m.Context(to_pkg_params(oracle.CFG3), backend=m.BACKEND_FP64_FFT)
+    with pytest.raises(m.TfheError) as e:   # the complex transform's kernels exist at N = 512 and 1024
+        m.Context(to_pkg_params(oracle.CFG5), backend=m.BACKEND_FP64_FFT)
     assert e.value.status == m.TFHE_ERR_UNSUPPORTED
     with pytest.raises(m.TfheError) as e:   # N = 1024, 2 levels of 2^16: error bound 2.5 > 1/4
         m.Context(m.TfheParams(1, 10, 2, m.DecomposerParams(16, 2)), backend=m.BACKEND_FP64_FFT)
@@ -604,7 +604,7 @@ def test_many_full_size_samples_against_the_oracle_on_all_host_cores(oracle, cfg
 
 
 @pytest.mark.parametrize("cfg,fast,count,slow_count", [("cfg3", "fp64-p49", 16384, 2048), ("cfg2", "fp64-fft", 8192, 2048),
-                                                       ("cfg5", "fp64-p42", 1024, 256), ("cfg1", "fp64-p42", 8192, 2048)])
+                                                       ("cfg5", "fp64-p42", 1024, 256), ("cfg1", "fp64-fft", 8192, 2048)])
 def test_fields_agree_on_large_batches(oracle, cfg, fast, count, slow_count):
     """Independent arithmetic, same bits: `count` random full-size bootstraps in the field AUTO
     picks against the 42-bit fp64 field where AUTO picks another one, and the first `slow_count` of them against

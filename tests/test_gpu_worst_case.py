@@ -58,7 +58,7 @@ def open_context(oracle, k, logn, pbs, backend, n=1):
         if e.status == m.TFHE_ERR_EXACTNESS:
             pytest.skip("outside this field's exactness bound: tfhe_context_create refuses it")
         if e.status == m.TFHE_ERR_UNSUPPORTED and backend == "fp64-fft":
-            pytest.skip("the complex-FFT backend has kernels at N = 1024 only")
+            pytest.skip("the complex-FFT backend has kernels at N = 512 and 1024")
         raise
 
 

@@ -337,7 +337,7 @@ int tfhe_context_create_with_backend(const tfhe_params* params, int device, int 
   const bool gl_ok = convolution_bits(params, GlField::key_bits()) < GlField::exact_bits();
   const bool gls_ok = convolution_bits(params, GlSplitField::key_bits()) < GlSplitField::exact_bits();
   // the complex transform is exact while the proven rounding error of an output coefficient stays below
-  // FftField::kMaxError (field_fft.h); its kernels exist at N = 1024
+  // FftField::kMaxError (field_fft.h); its kernels exist at N = 512 and 1024
   const bool fft_ok = launch::field_shape_supported(launch::kFieldFft, params->glwe_poly_degree) &&
                       params->pbs_decomposer.log_base <= (uint32_t)FftField::kMaxLogBase &&
                       FftField::error_bound((int)params->glwe_poly_degree,
@@ -352,8 +352,11 @@ int tfhe_context_create_with_backend(const tfhe_params* params, int device, int 
     else if (env && std::strcmp(env, "goldilocks-split") == 0) backend = TFHE_BACKEND_GOLDILOCKS_SPLIT;
     else if (env && std::strcmp(env, "fp64-fft") == 0) backend = TFHE_BACKEND_FP64_FFT;
   }
+  // AUTO: the complex transform first, except where the single-spectrum 49-bit field is exact at N = 512: with
+  // many digit rows the key stream decides, and fp64-fft's two spectra per key polynomial make it twice as
+  // long (the reference's default parameters: 145.7 ms against 77 ms per 4096 bootstraps)
   if (backend == TFHE_BACKEND_AUTO)
-    field = fft_ok  ? launch::kFieldFft
+    field = (fft_ok && !(params->glwe_poly_degree == 9 && fp49_ok)) ? launch::kFieldFft
             : fp49_ok ? launch::kFieldFp49
             : fp_ok ? launch::kFieldFp64
             : gl_ok ? launch::kFieldGoldilocks

@@ -31,12 +31,12 @@ struct GroupOf {
 
 // Shapes a transform policy is instantiated for.  The complex transform (field_fft.h) holds two
 // coefficients per element, so its N/2-point transform has 8 elements per lane at N = 1024 with one wave
-// per polynomial; N = 512 would leave 4 (the register passes need 8); N = 2048 over two waves (8 elements per lane again) is
+// per polynomial and 4 at N = 512 (four register passes of two bits); N = 2048 over two waves (8 elements per lane again) is
 // bit-exact but leaves one 6-wave team per CU and measured 137 ms against the 42-bit field's 77 ms per 1024
 // cfg5 bootstraps (profiles/r02_kernel_ab.txt), so it is not instantiated.
 template <class F, int LOGN>
 constexpr bool field_shape_ok() {
-  return F::kLogShrink == 0 || LOGN == 10;
+  return F::kLogShrink == 0 || LOGN == 10 || LOGN == 9;
 }
 
 // bytes of the twiddle table of a field at ring degree 2^LOGN
@@ -843,7 +843,7 @@ bool shape_supported_bmmp(u32 log_n, u32 k) { return log_n == 9 && (k == 1 || k 
 
 int field_parts(int field) { return (field == kFieldGoldilocks || field == kFieldFp49) ? 1 : 2; }
 
-bool field_shape_supported(int field, u32 log_n) { return field != kFieldFft || log_n == 10; }
+bool field_shape_supported(int field, u32 log_n) { return field != kFieldFft || log_n == 10 || log_n == 9; }
 
 // (field, log_n, k) -> template instantiation.  TFHE_DEV_CFG2_ONLY builds just the BASELINE cfg2
 // shape (N = 1024, k = 1) for fast iteration on the kernels.

@@ -58,7 +58,7 @@ struct NttShape {
   static constexpr int kTBits = (G == 1) ? 6 : (G == 2) ? 7 : 8;
   static constexpr int kEBits = LOGN - kTBits;
   static constexpr int kE = 1 << kEBits;
-  static_assert(kEBits >= 3 && kEBits <= 5, "8..32 elements per lane");
+  static_assert(kEBits >= 2 && kEBits <= 5, "4..32 elements per lane (4: the complex transform at N = 512, four register passes)");
   // three register passes cover 3e index bits; a fourth one (N = 2048 over 4 waves: e = 3) takes
   // the remaining low bits
   static constexpr int kPasses = (kTBits <= 2 * kEBits) ? 3 : 4;
@@ -284,6 +284,10 @@ struct TopConsts {
 template <int LOGN, int G>
 TFHE_HD int ntt_swizzle(int j) {
   if (G == 1 && LOGN == 10) return j ^ ((j >> 4) & 31);
+  // 256 16-byte elements, 4 per lane (the complex transform at N = 512): best linear map of bits 4..7 into the
+  // 16-byte slot number under the b128 banking rules -- every read and all but the last window's writes (2-way)
+  // conflict free (tools/ntt_model.py rules; search in profiles/r02_kernel_ab.txt)
+  if (G == 1 && LOGN == 8) return j ^ (((j >> 4) & 1) * 13) ^ (((j >> 5) & 1) * 4) ^ (((j >> 6) & 1) * 2);
   if (G == 1 && LOGN == 9) return j ^ ((j >> 3) & 7) ^ (((j >> 6) & 3) << 3);
   if (G == 1 && LOGN == 11) return j ^ ((j >> 5) & 31);
   if (G == 2 && LOGN == 11) return j ^ ((j >> 1) & 7) ^ ((j >> 4) & 31);

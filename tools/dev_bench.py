@@ -11,7 +11,7 @@ from oracle import oracle as orc
 orc.set_poly_mul_mode(1)
 which = sys.argv[1]
 BACKEND = getattr(m, os.environ.get('DEV_BACKEND', 'BACKEND_FP64'))
-cfg = {"cfg2": (1, 10, 630, (7, 3), 4096), "cfg3": (2, 9, 722, (4, 6), 4096), "cfg5": (2, 11, 630, (8, 4), 1024)}[which]
+cfg = {"cfg1": (1, 9, 500, (8, 2), 4096), "cfg2": (1, 10, 630, (7, 3), 4096), "cfg3": (2, 9, 722, (4, 6), 4096), "cfg5": (2, 11, 630, (8, 4), 1024)}[which]
 k, logn, n, pbs, batch = cfg
 # parity on a short key first
 ps = orc.Params(k, logn, 4, orc.Decomposer(*pbs)); pp = m.TfheParams(k, logn, 4, m.DecomposerParams(*pbs))
