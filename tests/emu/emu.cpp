@@ -5,6 +5,7 @@
 // `pytest -m "not gpu"` check the exact device code (layouts, twiddles, swizzles, decomposer,
 // rotation signs) bit-for-bit against the oracle without a GPU.  It is a test of the product's
 // source, not a fallback: nothing in the shipped library can reach it.
+#define TFHE_FFT_TRACK_ERROR 1  // record how far the complex transform's lifted values are from integers
 #include <pthread.h>
 
 #include <cstdlib>
@@ -270,6 +271,9 @@ int emu_field_shape_ok(int field, int logn, int g) {
   return ((logn == 9 || logn == 10) && g == 1) || (logn == 11 && (g == 1 || g == 2));
 }
 double emu_fft_error_bound(int logn, int rows, int log_base) { return FftField::error_bound(logn, rows, log_base); }
+// largest |value - nearest integer| the complex transform has lifted since the last reset
+void emu_fft_error_reset() { fft_error_slot().store(0.0); }
+double emu_fft_error_max() { return fft_error_slot().load(); }
 
 int emu_poly_ntt(int field, int logn, int g, const void* in, void* out, int inverse) {
   DISPATCH_FIELD(field, DISPATCH_LOGN(logn, g, (poly_ntt<FF, L, GG>((const FF::elem*)in, (FF::elem*)out, inverse))));

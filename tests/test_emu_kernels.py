@@ -283,6 +283,46 @@ def test_external_product_worst_case_magnitudes(emu, oracle, field, k, logn, pbs
         assert np.array_equal(out, oracle.external_product(params, ggsw, glwe)), hex(key_word)
 
 
+@pytest.mark.parametrize("k,logn,pbs,g", [(1, 10, (7, 3), 1), (1, 9, (8, 2), 1), (2, 9, (4, 6), 1), (2, 11, (8, 4), 2)])
+def test_fft_rounding_margin(emu, oracle, k, logn, pbs, g):
+    """The complex-FFT backend is exact because every lifted value is within 1/2 of the integer it stands for.
+    field_fft.h proves a bound (FftField::error_bound, admitted below 1/4); this measures the distance the emulator
+    actually sees -- on operands at the magnitude bound and on random ones -- and holds it against that bound, and
+    the Python restatement of the bound against the C++ one."""
+    emu.emu_fft_error_bound.restype = C.c_double
+    emu.emu_fft_error_max.restype = C.c_double
+    log_base, levels = pbs
+    rows = (k + 1) * levels
+    bound = emu.emu_fft_error_bound(logn, rows, log_base)
+    assert abs(bound - fft_error_bound(logn, rows, log_base)) < 1e-12 * bound
+    assert bound < 0.25
+    params = oracle.Params(k, logn, 1, oracle.Decomposer(*pbs))
+    N = params.N
+    rng = np.random.default_rng(logn + 7 * k)
+    cand = rng.integers(0, 1 << 32, size=100000, dtype=np.uint64).astype(np.uint32)
+    d = oracle.decompose(oracle.Decomposer(*pbs), cand).astype(np.int32).astype(np.int64).sum(axis=1)
+    wpos, wneg = int(cand[int(d.argmax())]), int(cand[int(d.argmin())])
+    worst = 0.0
+    cases = [(kw, gw) for kw in (0x7FFF7FFF, 0x80008000, 0x7FFF8000) for gw in (wpos, wneg)] + [(None, None)] * 2
+    for key_word, glwe_word in cases:
+        if key_word is None:
+            ggsw = rng.integers(0, 1 << 32, size=(params.R, k + 1, N), dtype=np.uint64).astype(np.uint32)
+            glwe = rng.integers(0, 1 << 32, size=(k + 1, N), dtype=np.uint64).astype(np.uint32)
+        else:
+            ggsw = np.full((params.R, k + 1, N), key_word, dtype=np.uint32)
+            ggsw[:, :, 1:] = (np.uint32(0) - ggsw[:, :, 1:]).astype(np.uint32)
+            glwe = np.full((k + 1, N), glwe_word, dtype=np.uint32)
+        spec = prepared(emu, FFT, params, ggsw, g)
+        out = np.zeros_like(glwe)
+        emu.emu_fft_error_reset()
+        assert emu.emu_external_product(FFT, g, k, logn, log_base, levels, p64(spec), p32(glwe), p32(out)) == 0
+        worst = max(worst, emu.emu_fft_error_max())
+        assert np.array_equal(out, oracle.external_product(params, ggsw, glwe))
+    # measured distance from the integers: orders of magnitude inside the proven bound, itself inside 1/4
+    assert worst < bound / 100, (worst, bound)
+    print(f"fft rounding margin N=2^{logn} k={k} rows={rows} B=2^{log_base}: measured {worst:.3g}, proven bound {bound:.3g}")
+
+
 @pytest.mark.parametrize("field", FIELDS)
 @pytest.mark.parametrize("k,logn,n,pbs,log_p,g", CASES)
 def test_blind_rotate_and_extract_vs_oracle(emu, oracle, exchange_buffers, field, k, logn, n, pbs, log_p, g):

@@ -37,6 +37,9 @@
 #pragma once
 #include <math.h>
 
+#if defined(TFHE_FFT_TRACK_ERROR) && !defined(__HIPCC__)
+#include <atomic>
+#endif
 #include <vector>
 
 #include "platform.h"
@@ -46,6 +49,22 @@ namespace tfhe {
 struct alignas(16) cplx {
   double re, im;
 };
+
+#if defined(TFHE_FFT_TRACK_ERROR) && !defined(__HIPCC__)
+// Host emulator only: the largest |t - rint(t)| seen by FftField::to_u32 since the last reset -- the measured
+// counterpart of error_bound() (tests/test_emu_kernels.py::test_fft_rounding_margin).
+inline std::atomic<double>& fft_error_slot() {
+  static std::atomic<double> worst{0.0};
+  return worst;
+}
+inline void fft_track_error(double t) {
+  const double e = fabs(t - rint(t));
+  std::atomic<double>& w = fft_error_slot();
+  double cur = w.load(std::memory_order_relaxed);
+  while (e > cur && !w.compare_exchange_weak(cur, e, std::memory_order_relaxed)) {
+  }
+}
+#endif
 
 struct FftField {
   typedef cplx elem;
@@ -106,6 +125,9 @@ struct FftField {
   // |t| < 2^51, t within 1/4 of an integer -> that integer mod 2^32: t + 1.5 * 2^52 rounds to nearest in
   // [2^52, 2^53), where doubles are the integers; the low 32 bits of the sum's mantissa are the answer
   TFHE_HD static u32 to_u32(double t) {
+#if defined(TFHE_FFT_TRACK_ERROR) && !defined(__HIP_DEVICE_COMPILE__)
+    fft_track_error(t);  // tests/emu only: distance of every lifted value from the integer it rounds to
+#endif
     const double shifted = t + 6755399441055744.0;  // 1.5 * 2^52
     u64 bits;
     __builtin_memcpy(&bits, &shifted, sizeof(bits));
