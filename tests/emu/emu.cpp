@@ -85,6 +85,7 @@ void run_team(int logn, int groups, int g, const std::function<void(const HostWa
       case 11 * 8 + 2: ntt_stage_twiddles<11, 2>(team.tw.data(), natural.data(), tid, 64); break;
       case 11 * 8 + 4: ntt_stage_twiddles<11, 4>(team.tw.data(), natural.data(), tid, 64); break;
       case 8 * 8 + 1: ntt_stage_twiddles<8, 1>(team.tw.data(), natural.data(), tid, 64); break;  // complex transform, N = 512
+      case 10 * 8 + 4: ntt_stage_twiddles<10, 4>(team.tw.data(), natural.data(), tid, 64); break;  // ... over four waves
       case 10 * 8 + 2: ntt_stage_twiddles<10, 2>(team.tw.data(), natural.data(), tid, 64); break;  // complex transform, N = 2048
       default: std::abort();
     }
@@ -109,7 +110,7 @@ void run_team(int logn, int groups, int g, const std::function<void(const HostWa
 // coefficients per element, so it needs N/2 >= 512 points per G waves x 8 elements
 template <class F, int LOGN, int G>
 constexpr bool shape_ok() {
-  return F::kLogShrink == 0 || ((LOGN == 9 || LOGN == 10) && G == 1) || (LOGN == 11 && (G == 1 || G == 2));
+  return F::kLogShrink == 0 || ((LOGN == 9 || LOGN == 10) && G == 1) || LOGN == 11;
 }
 
 template <class F, int LOGN, int G>
@@ -268,7 +269,7 @@ int emu_field_parts(int field) { return (field == 1 || field == 4) ? 1 : 2; }
 // 1 if the emulator can run `field` at ring degree 2^logn with g waves per polynomial
 int emu_field_shape_ok(int field, int logn, int g) {
   if (field != 5) return 1;
-  return ((logn == 9 || logn == 10) && g == 1) || (logn == 11 && (g == 1 || g == 2));
+  return ((logn == 9 || logn == 10) && g == 1) || logn == 11;
 }
 double emu_fft_error_bound(int logn, int rows, int log_base) { return FftField::error_bound(logn, rows, log_base); }
 // largest |value - nearest integer| the complex transform has lifted since the last reset

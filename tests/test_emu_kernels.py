@@ -42,7 +42,7 @@ def field_exact(field, k, logn, pbs, g=1):
     rows = (k + 1) * pbs[1]
     bits = math.log2(rows) + logn + pbs[0]
     if field == FFT:
-        shape = (logn in (9, 10) and g == 1) or (logn == 11 and g in (1, 2))
+        shape = (logn in (9, 10) and g == 1) or logn == 11
         return shape and pbs[0] <= 16 and fft_error_bound(logn, rows, pbs[0]) < 0.25
     if field == FP:
         return bits + 15 < 40.9 and pbs[0] <= 9

@@ -20,20 +20,24 @@ namespace {
 #ifndef TFHE_GROUP_N2048
 #define TFHE_GROUP_N2048 4
 #endif
+#ifndef TFHE_GROUP_N2048_FFT
+#define TFHE_GROUP_N2048_FFT 4
+#endif
 // (N = 1024 over two waves was measured too: 97.9 ms against 64.0 ms per cfg2 batch -- a fourth
 // register pass and cross-wave barriers cost more than the third wave per SIMD gives.)
 template <class F, int LOGN>
 struct GroupOf {
   // the complex transform has N/2 elements of 16 bytes: two waves per polynomial at N = 2048 hold 8 of
   // them per lane and array (the register footprint of one wave at N = 1024)
-  static constexpr int value = (LOGN >= 11) ? (F::kLogShrink ? 2 : TFHE_GROUP_N2048) : 1;
+  static constexpr int value = (LOGN >= 11) ? (F::kLogShrink ? TFHE_GROUP_N2048_FFT : TFHE_GROUP_N2048) : 1;
 };
 
 // Shapes a transform policy is instantiated for.  The complex transform (field_fft.h) holds two
 // coefficients per element, so its N/2-point transform has 8 elements per lane at N = 1024 with one wave
-// per polynomial and 4 at N = 512 (four register passes of two bits); N = 2048 over two waves (8 elements per lane again) is
-// bit-exact but leaves one 6-wave team per CU and measured 137 ms against the 42-bit field's 77 ms per 1024
-// cfg5 bootstraps (profiles/r02_kernel_ab.txt), so it is not instantiated.
+// per polynomial and 4 at N = 512 (four register passes of two bits); N = 2048 is bit-exact both over two waves per
+// polynomial (8 elements per lane, one 6-wave team per CU: 137 ms per 1024 cfg5 bootstraps) and over four (4 elements
+// per lane, five register passes, 12 waves: 79.2 ms) but does not beat the 42-bit field's 77.2 ms -- a 12-wave team
+// is bound by its barriers, not its arithmetic (profiles/r02_kernel_ab.txt) -- so it is not instantiated.
 template <class F, int LOGN>
 constexpr bool field_shape_ok() {
   return F::kLogShrink == 0 || LOGN == 10 || LOGN == 9;
@@ -843,7 +847,7 @@ bool shape_supported_bmmp(u32 log_n, u32 k) { return log_n == 9 && (k == 1 || k 
 
 int field_parts(int field) { return (field == kFieldGoldilocks || field == kFieldFp49) ? 1 : 2; }
 
-bool field_shape_supported(int field, u32 log_n) { return field != kFieldFft || log_n == 10 || log_n == 9; }
+bool field_shape_supported(int field, u32 log_n) { return field != kFieldFft || log_n == 9 || log_n == 10; }
 
 // (field, log_n, k) -> template instantiation.  TFHE_DEV_CFG2_ONLY builds just the BASELINE cfg2
 // shape (N = 1024, k = 1) for fast iteration on the kernels.

@@ -59,15 +59,18 @@ struct NttShape {
   static constexpr int kEBits = LOGN - kTBits;
   static constexpr int kE = 1 << kEBits;
   static_assert(kEBits >= 2 && kEBits <= 5, "4..32 elements per lane (4: the complex transform at N = 512, four register passes)");
-  // three register passes cover 3e index bits; a fourth one (N = 2048 over 4 waves: e = 3) takes
-  // the remaining low bits
-  static constexpr int kPasses = (kTBits <= 2 * kEBits) ? 3 : 4;
-  static_assert(kTBits <= 3 * kEBits, "four register passes must cover all index bits");
-  // window lows of the passes (forward order); kLo4 is only used when kPasses == 4
+  // a register pass covers e index bits: three passes (most shapes), four (N = 2048 over 4 waves: e = 3; the
+  // complex transform at N = 512: 256 points, e = 2) or five (the complex transform at N = 2048 over 4 waves:
+  // 1024 points, e = 2); the last pass takes whatever low bits remain
+  static constexpr int kPasses = (LOGN + kEBits - 1) / kEBits;
+  static_assert(kPasses >= 3 && kPasses <= 5, "three to five register passes");
+  // window lows of the passes (forward order): pass p works in window [lo(p), lo(p) + e)
+  static constexpr int lo(int p) { return LOGN - p * kEBits > 0 ? LOGN - p * kEBits : 0; }
   static constexpr int kLo1 = kTBits;
-  static constexpr int kLo2 = kTBits - kEBits;
-  static constexpr int kLo3 = (kPasses == 3) ? 0 : kTBits - 2 * kEBits;
-  static constexpr int kLo4 = 0;
+  static constexpr int kLo2 = lo(2);
+  static constexpr int kLo3 = lo(3);
+  static constexpr int kLo4 = lo(4);
+  static constexpr int kLo5 = 0;
 };
 
 // Where the working copy of the twiddle table (LDS on the GPU) keeps psi_rev[idx].  Stage b of a
@@ -83,7 +86,7 @@ struct NttShape {
 template <int LOGN, int G>
 TFHE_HD int ntt_stage_window_lo(int b) {
   using S = NttShape<LOGN, G>;
-  return b >= S::kLo1 ? S::kLo1 : b >= S::kLo2 ? S::kLo2 : b >= S::kLo3 ? S::kLo3 : S::kLo4;
+  return b >= S::kLo1 ? S::kLo1 : b >= S::kLo2 ? S::kLo2 : b >= S::kLo3 ? S::kLo3 : b >= S::kLo4 ? S::kLo4 : S::kLo5;
 }
 
 #ifndef TFHE_TW_TRANSPOSED
@@ -288,6 +291,10 @@ TFHE_HD int ntt_swizzle(int j) {
   // 16-byte slot number under the b128 banking rules -- every read and all but the last window's writes (2-way)
   // conflict free (tools/ntt_model.py rules; search in profiles/r02_kernel_ab.txt)
   if (G == 1 && LOGN == 8) return j ^ (((j >> 4) & 1) * 13) ^ (((j >> 5) & 1) * 4) ^ (((j >> 6) & 1) * 2);
+  // 1024 16-byte elements over four waves, 4 per lane (the complex transform at N = 2048, emulator-tested, not
+  // instantiated on the GPU): the same kind of map over index bits 4..9
+  if (G == 4 && LOGN == 10)
+    return j ^ (((j >> 4) & 1) * 13) ^ (((j >> 5) & 1) * 4) ^ (((j >> 6) & 1) * 2) ^ (((j >> 7) & 1) * 15) ^ (((j >> 8) & 1) * 2);
   if (G == 1 && LOGN == 9) return j ^ ((j >> 3) & 7) ^ (((j >> 6) & 3) << 3);
   if (G == 1 && LOGN == 11) return j ^ ((j >> 5) & 31);
   if (G == 2 && LOGN == 11) return j ^ ((j >> 1) & 7) ^ ((j >> 4) & 31);
@@ -484,9 +491,13 @@ TFHE_HD void ntt_forward(const Ctx& c, typename F::elem (&x)[NttShape<LOGN, G>::
   ntt_pass_forward<F, LOGN, G, S::kLo2, S::kTBits - 1, S::kLo2, false>(c, x, top);
   ntt_transpose<F, LOGN, G, S::kLo2, S::kLo3>(c, x);
   ntt_pass_forward<F, LOGN, G, S::kLo3, S::kLo2 - 1, S::kLo3, false>(c, x, top);
-  if constexpr (S::kPasses == 4) {
+  if constexpr (S::kPasses >= 4) {
     ntt_transpose<F, LOGN, G, S::kLo3, S::kLo4>(c, x);
-    ntt_pass_forward<F, LOGN, G, S::kLo4, S::kLo3 - 1, 0, false>(c, x, top);
+    ntt_pass_forward<F, LOGN, G, S::kLo4, S::kLo3 - 1, S::kLo4, false>(c, x, top);
+  }
+  if constexpr (S::kPasses == 5) {
+    ntt_transpose<F, LOGN, G, S::kLo4, S::kLo5>(c, x);
+    ntt_pass_forward<F, LOGN, G, S::kLo5, S::kLo4 - 1, 0, false>(c, x, top);
   }
 }
 
@@ -501,8 +512,12 @@ TFHE_HD void ntt_forward(const Ctx& c, typename F::elem (&x)[NttShape<LOGN, G>::
 template <class F, int LOGN, int G, class Ctx, class Top>
 TFHE_HD void ntt_inverse(const Ctx& c, typename F::elem (&x)[NttShape<LOGN, G>::kE], const Top& top) {
   using S = NttShape<LOGN, G>;
-  if constexpr (S::kPasses == 4) {
-    ntt_pass_inverse<F, LOGN, G, S::kLo4, S::kLo3 - 1, 0>(c, x, top);
+  if constexpr (S::kPasses == 5) {
+    ntt_pass_inverse<F, LOGN, G, S::kLo5, S::kLo4 - 1, 0>(c, x, top);
+    ntt_transpose<F, LOGN, G, S::kLo5, S::kLo4>(c, x);
+  }
+  if constexpr (S::kPasses >= 4) {
+    ntt_pass_inverse<F, LOGN, G, S::kLo4, S::kLo3 - 1, S::kLo4>(c, x, top);
     ntt_transpose<F, LOGN, G, S::kLo4, S::kLo3>(c, x);
   }
   ntt_pass_inverse<F, LOGN, G, S::kLo3, S::kLo2 - 1, S::kLo3>(c, x, top);
