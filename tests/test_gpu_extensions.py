@@ -13,7 +13,7 @@ from test_gpu_keygen import glwe_samples, lwe_samples
 
 pytestmark = pytest.mark.gpu
 
-BACKENDS = {"fp64": 2, "goldilocks": 1, "goldilocks-split": 3}
+BACKENDS = {"fp64": 2, "goldilocks": 1, "goldilocks-split": 3, "fp64-fft": 5}
 
 
 @pytest.mark.parametrize("backend", list(BACKENDS))
@@ -26,6 +26,11 @@ def test_aligned_decomposer_matches_oracle(oracle, k, logn, n, pbs, ks, backend)
     glwe = rand_u32(rng, (3, k + 1, p.N))
     glwe[0, :, :4] = [0xFFFFFFFF, 0x7FFFFFFF, 0x80000000, 0xF8F8F8F8]
     vals = rand_u32(rng, 300)
+    # (with the aligned decomposer the blind rotation at cfg2's shape really depends on the key: in the literal mode
+    # the top four bits of a word are never decomposed, a trivial accumulator has nothing below them, every digit is
+    # zero and the CMUXes leave it alone -- the external-product and keygen tests carry the arithmetic there)
+    if backend == "fp64-fft" and logn == 11:
+        pytest.skip("the complex-FFT backend has kernels at N = 512 and 1024")
     with m.Context(to_pkg_params(p), backend=BACKENDS[backend]) as ctx:
         ctx.set_decomposer_alignment(True)
         ctx.load_bootstrapping_key(bsk, ksk)
