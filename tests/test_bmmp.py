@@ -77,13 +77,14 @@ def test_device_headers_vs_oracle_twin(emu, oracle, field, k, n, pbs, log_p):
 
 
 # ------------------------------------------------------------------------------------------- GPU
-BACKENDS = ["auto", "fp64", "fp64-p49", "goldilocks", "goldilocks-split"]
+BACKENDS = ["auto", "fp64", "fp64-p49", "fp64-fft", "goldilocks", "goldilocks-split"]
 
 
 def backend_id(name):
     m = pkg()
     return {"fp64": m.BACKEND_FP64, "goldilocks": m.BACKEND_GOLDILOCKS, "auto": m.BACKEND_AUTO,
-            "goldilocks-split": m.BACKEND_GOLDILOCKS_SPLIT, "fp64-p49": m.BACKEND_FP64_P49}[name]
+            "goldilocks-split": m.BACKEND_GOLDILOCKS_SPLIT, "fp64-p49": m.BACKEND_FP64_P49,
+            "fp64-fft": m.BACKEND_FP64_FFT}[name]
 
 
 @pytest.mark.gpu
