@@ -35,6 +35,7 @@
 // The 32-bit key word is split into signed 16-bit halves like in field_fp.h (two spectra per key
 // polynomial): with the word taken whole the bound is 2^16 times larger and fails.
 #pragma once
+#include <float.h>
 #include <math.h>
 
 #if defined(TFHE_FFT_TRACK_ERROR) && !defined(__HIPCC__)
@@ -142,6 +143,8 @@ struct FftField {
   // out: m + 18 elements (wave_ntt.h::ntt_twiddle_words) for a transform of m = 2^logm points
   static inline void fill_twiddles(int logm, elem* out) {
     const int m = 1 << logm;
+    // the bound's twiddle accuracy (each component correctly rounded to double) rests on an 80-bit long double
+    static_assert(LDBL_MANT_DIG >= 64, "twiddles are rounded from a 64-bit-mantissa long double");
     const long double pi = 3.14159265358979323846264338327950288L;
     out[0] = elem{1.0, 0.0};
     for (int s = 0; (1 << s) < m; ++s) {
