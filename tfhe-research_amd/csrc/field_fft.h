@@ -144,7 +144,9 @@ struct FftField {
   static inline void fill_twiddles(int logm, elem* out) {
     const int m = 1 << logm;
     // the bound's twiddle accuracy (each component correctly rounded to double) rests on an 80-bit long double
+#if !defined(__HIP_DEVICE_COMPILE__)  // (host function; the device pass of hipcc parses it with long double = double)
     static_assert(LDBL_MANT_DIG >= 64, "twiddles are rounded from a 64-bit-mantissa long double");
+#endif
     const long double pi = 3.14159265358979323846264338327950288L;
     out[0] = elem{1.0, 0.0};
     for (int s = 0; (1 << s) < m; ++s) {
