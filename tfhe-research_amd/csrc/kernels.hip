@@ -117,6 +117,9 @@ struct DeviceWave {
 #ifndef TFHE_WAVES_PER_SIMD_FP
 #define TFHE_WAVES_PER_SIMD_FP 2
 #endif
+#ifndef TFHE_WAVES_PER_SIMD_E8  // shapes with 8 ring coefficients per lane and array
+#define TFHE_WAVES_PER_SIMD_E8 3
+#endif
 
 // One workgroup = one team = K+1 polynomial groups of G waves = one LWE sample.
 // LDS (dynamic, 16-B aligned base, no static LDS): [ twiddles (N+2) x 8 B ][ group c: EXB transpose/
@@ -145,8 +148,8 @@ struct TeamCfg {
   // room for the largest table: (N + 18) 8-byte elements or (N/2 + 18) 16-byte ones
   static constexpr size_t kTwBytes = (size_t)N * 8 + 18 * 16;  // multiple of 16
   static constexpr size_t kLds = kTwBytes + (size_t)(K + 1) * kGroupLds;
-  static constexpr int kMinWavesGl = (NttShape<LOGN, G>::kE == 8) ? 3 : TFHE_WAVES_PER_SIMD_GL;
-  static constexpr int kMinWavesFp = (NttShape<LOGN, G>::kE == 8) ? 3 : TFHE_WAVES_PER_SIMD_FP;
+  static constexpr int kMinWavesGl = (NttShape<LOGN, G>::kE == 8) ? TFHE_WAVES_PER_SIMD_E8 : TFHE_WAVES_PER_SIMD_GL;
+  static constexpr int kMinWavesFp = (NttShape<LOGN, G>::kE == 8) ? TFHE_WAVES_PER_SIMD_E8 : TFHE_WAVES_PER_SIMD_FP;
 };
 
 template <class F, int LOGN, int K>
