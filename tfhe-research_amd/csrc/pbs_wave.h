@@ -134,7 +134,7 @@ TFHE_HD u32 monomial_coeff(const u32* poly, int j, u32 m) {
 // waves.  Two workgroup barriers per level (publish -> consume -> reuse of the buffer).
 //
 //   src(j)  -> coefficient j of polynomial c of the GLWE operand (functor, lane-local)
-//   ggsw    -> prepared GGSW: [R][K+1][F::kParts] spectra of N elements in spectrum_slot order,
+//   ggsw    -> prepared GGSW: [R][K+1][F::kParts] spectra of N field elements (N/2 complex ones) in spectrum_slot order,
 //              pre-scaled by N^-1 (so the unscaled inverse NTT lands on the true product)
 //   out(j, value mod 2^32) is called once per coefficient of output polynomial c.
 // Every wave of the team must call this the same number of times (it contains barriers).
@@ -181,8 +181,6 @@ TFHE_HD void external_product_team_keys(const Ctx& c, const PbsParams& P, const 
       if (SPLIT) accum_lo[SPLIT ? q : 0][SPLIT ? r : 0] = F::zero();
     }
 
-  // v[r]: rounded coefficient; hb[r]: carry state of its digit chain (decompose_limb_fast), 0 before
-  // the lowest kept limb (whose carry-in is 0 by construction)
   // v[r]: rounded coefficient; once a limb has been consumed its bit log_base-1 carries the digit
   // chain's carry to the next limb (decompose_limb_fast)
   // The lane-uniform constants of the forward transforms' top window (wave_ntt.h::TopConsts) are fetched

@@ -1,11 +1,14 @@
-// wave_ntt.h -- exact negacyclic NTT of one polynomial held by a GROUP of G 64-lane wavefronts
+// wave_ntt.h -- negacyclic transform of one polynomial held by a GROUP of G 64-lane wavefronts
 // (G = 1: one wave per polynomial, no barrier inside a transform; G = 4 for N = 2048 so that a lane
 // holds only 8 elements per array and three waves fit a SIMD; G = 2 is kept and tested as well).
+// The same passes serve the exact NTTs over the prime fields (8-byte elements, one per ring coefficient) and
+// the complex FFT of field_fft.h (16-byte elements, one per PAIR of coefficients: LOGN below is then the log
+// of the transform size N/2, and "psi" stands for the table of roots of i described there).
 //
-// N = 2^LOGN coefficients live in E = N/(64 G) registers per lane (8 bytes each); below "tid" is the
+// N = 2^LOGN elements live in E = N/(64 G) registers per lane; below "tid" is the
 // thread index inside the group (0 .. 64G-1) and TB = log2(64 G).  The transform is the
 // merged-psi Cooley-Tukey NTT (natural order in, bit-reversed order out) and its Gentleman-Sande
-// inverse, executed as three "register passes" (four when e = 3 does not cover TB = 8 bits twice).  A pass owns a window of e = log2(E) index bits:
+// inverse, executed as three to five "register passes" (ceil(LOGN / e)).  A pass owns a window of e = log2(E) index bits:
 // in window [LO, LO+e) a lane holds the E indices that differ only in those bits,
 //     j = (hi << (LO+e)) | (r << LO) | lo,   lane = (hi << LO) | lo,   r = register number,
 // so every butterfly of the stages on those bits is lane-local.  Between passes the polynomial
@@ -27,8 +30,9 @@
 // The table has kTwiddleWords = N + 2 elements: [N], [N+1] hold psi_rev[1]*psi_rev[2] and
 // psi_rev[1]*psi_rev[3] for the fused first two stages.
 //
-// The arithmetic is a field policy F (field_gl.h: Goldilocks u64, field_fp.h: 42-bit prime in
-// fp64); elements are 8 bytes in both, so layouts, swizzles and LDS budgets are identical.
+// The arithmetic is a policy class F (field_gl.h: Goldilocks u64; field_fp.h / field_fp49.h: 42- and 49-bit
+// primes in fp64; field_fft.h: complex numbers); a polynomial takes 8 N bytes in every one of them, so the LDS
+// budgets are identical; swizzles and the twiddle order are chosen per element size.
 //
 // Ctx (GPU: DeviceWave in kernels.hip; CPU tests: the SIMT emulator in tests/emu) provides
 //   int tid() const;  void poly_sync() const;  void wave_sync() const;  elem* scratch() const;
