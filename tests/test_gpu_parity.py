@@ -632,3 +632,40 @@ def test_fields_agree_on_large_batches(oracle, cfg, fast, count, slow_count):
             ctx.set_stream(None)
     for name, _, c in runs[1:]:
         assert torch.equal(outs["auto"][:c], outs[name]), name
+
+
+def test_backends_agree_at_full_size_cfg2_with_a_key_dependent_rotation(oracle):
+    """BASELINE cfg2 (N=1024, k=1, n=630, l=3, log2 B=7) with the ALIGNED decomposer: in the literal mode a trivial
+    accumulator has no bit below 2^29 while bits 28..31 are never decomposed, so every digit is zero and the blind
+    rotation ignores the key; aligned, all 630 CMUXes do real work.  4,096 random ciphertexts and a random
+    key through the complex-FFT backend and the 42-bit prime field, the first 512 also through both Goldilocks fields:
+    every output word equal, and three rows against the oracle in the same mode."""
+    import torch
+    p = oracle.CFG2
+    m = pkg()
+    lut = np.random.default_rng(7).integers(0, 1 << p.log_p, size=1 << p.log_p)
+    _, bsk, ksk, tv = oracle.synthetic_inputs(p, 1, cfg_index=2, lut=lut)
+    gen = torch.Generator(device="cuda:0").manual_seed(2024)
+    count, slow = 4096, 512
+    lwe = torch.randint(-(1 << 31), (1 << 31) - 1, (count, p.n + 1), dtype=torch.int32, device="cuda:0", generator=gen)
+    tv_d = torch.from_numpy(tv.view(np.int32)).to("cuda:0")
+    outs = {}
+    for name, b, c in (("fft", m.BACKEND_FP64_FFT, count), ("p42", m.BACKEND_FP64, count), ("gl", m.BACKEND_GOLDILOCKS, slow),
+                       ("gls", m.BACKEND_GOLDILOCKS_SPLIT, slow)):
+        with m.Context(to_pkg_params(p), backend=b) as ctx:
+            ctx.set_decomposer_alignment(True)
+            ctx.load_bootstrapping_key(bsk, ksk)
+            ctx.use_torch_stream()
+            outs[name] = ctx.bootstrap(lwe[:c].contiguous(), tv_d)
+            torch.cuda.synchronize()
+            ctx.set_stream(None)
+    assert torch.unique(outs["fft"]).numel() > 100000  # the rotation did depend on the data
+    assert torch.equal(outs["fft"], outs["p42"])
+    assert torch.equal(outs["fft"][:slow], outs["gl"]) and torch.equal(outs["fft"][:slow], outs["gls"])
+    host = outs["fft"][:3].cpu().numpy().view(np.uint32)
+    rows = lwe[:3].cpu().numpy().view(np.uint32)
+    with oracle.decomposer_aligned(True):
+        orc_mode = oracle
+        orc_mode.set_poly_mul_mode(1)
+        for b in range(3):
+            assert np.array_equal(host[b], orc_mode.bootstrap(p, rows[b], bsk, ksk, tv)), b
