@@ -348,6 +348,10 @@ int tfhe_file_read(const char *path, uint32_t *data, uint64_t words);
  * tfhe_context_set_timing(ctx, 1): the _device calls then record events (still no sync). */
 int tfhe_context_set_timing(tfhe_context *ctx, int enable);
 int tfhe_last_kernel_ms(tfhe_context *ctx, float *blind_rotate_ms, float *key_switch_ms);
+/* The same for the bootstrap (or gate) call made `steps_ago` timed calls before the last one (0 = the last; the
+ * context keeps the events of the last 64): K steps can be enqueued back to back and read afterwards, with no host
+ * synchronisation inside the timed loop. */
+int tfhe_kernel_ms_ago(tfhe_context *ctx, unsigned steps_ago, float *blind_rotate_ms, float *key_switch_ms);
 /* HBM roofline measured on this device now: a 16-byte-per-lane stream copy of `bytes` (two scratch
  * buffers are allocated and freed inside), `reps` timed launches on the context's stream;
  * *gb_per_s = (bytes read + bytes written) / time.  Synchronises. */

@@ -412,6 +412,13 @@ class Context:
         self._check(lib().tfhe_last_kernel_ms(self._h, C.byref(br), C.byref(ks)))
         return br.value, ks.value
 
+    def kernel_ms_ago(self, steps_ago: int):
+        """(blind rotation ms, key switch ms) of the timed bootstrap `steps_ago` calls before the last one; the context
+        keeps the last 64, so a timed loop needs no host synchronisation inside"""
+        br, ks = C.c_float(), C.c_float()
+        self._check(lib().tfhe_kernel_ms_ago(self._h, C.c_uint(steps_ago), C.byref(br), C.byref(ks)))
+        return br.value, ks.value
+
     # -- keys -----------------------------------------------------------------------------------
     def load_bootstrapping_key(self, bsk, ksk):
         """bsk [n][R][k+1][N], ksk [k*N*l_ks][n+1]: reference layouts (numpy or torch device)."""

@@ -73,7 +73,14 @@ struct tfhe_context {
   size_t key_tmp_words = 0;
 
   bool timing = false;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // br start/stop, ks start/stop
+  // br start/stop, ks start/stop of the current timing slot.  Bootstraps rotate through kTimingSlots sets of
+  // events, so that a caller can time K back-to-back steps without a host synchronisation inside the loop and
+  // read them all afterwards (tfhe_kernel_ms_ago); the other timed calls use the current set.
+  static constexpr int kTimingSlots = 64;
+  hipEvent_t ev_ring[kTimingSlots][4] = {};
+  hipEvent_t* ev = ev_ring[0];
+  int ev_slot = 0;
+  unsigned long long timed_bootstraps = 0;
   bool ev_valid_br = false, ev_valid_ks = false;
 
   std::string last_error;
@@ -222,6 +229,11 @@ int enqueue_bootstrap(tfhe_context* ctx, const u32* d_lwe_in, size_t batch, cons
                       size_t tv_count, u32* d_lwe_big, u32* d_lwe_out) {
   const u32* br_in = d_lwe_in;
   u32* br_out = d_lwe_big;
+  if (ctx->timing) {  // next slot of the ring
+    ctx->ev_slot = (ctx->ev_slot + 1) % tfhe_context::kTimingSlots;
+    ctx->ev = ctx->ev_ring[ctx->ev_slot];
+    ++ctx->timed_bootstraps;
+  }
   if (ctx->ks_first) {  // notes/TFHE.md:367-400: key switch k*N -> n, then PBS back to k*N
     if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
     HIP_TRY(ctx, launch::key_switch(ctx->stream, ctx->ks, ctx->big_n, ctx->params.lwe_dimension,
@@ -408,7 +420,8 @@ int tfhe_context_create_with_backend(const tfhe_params* params, int device, int 
   if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
     return bail(e, "hipStreamCreate");
   ctx->own_stream = true;
-  for (auto& ev : ctx->ev)
+  for (auto& slot : ctx->ev_ring)
+    for (auto& ev : slot)
     if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e, "hipEventCreate");
   e = field == launch::kFieldFp64   ? upload_twiddles<FpField>(ctx)
       : field == launch::kFieldFp49 ? upload_twiddles<Fp49Field>(ctx)
@@ -453,7 +466,8 @@ void tfhe_context_destroy(tfhe_context* ctx) {
     if (p) (void)hipFree(p);
   for (auto& g : ctx->gate_tvs)
     if (g.d_tv) (void)hipFree(g.d_tv);
-  for (auto& ev : ctx->ev)
+  for (auto& slot : ctx->ev_ring)
+    for (auto& ev : slot)
     if (ev) (void)hipEventDestroy(ev);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -517,6 +531,7 @@ int tfhe_context_set_timing(tfhe_context* ctx, int enable) {
   if (!ctx) return TFHE_ERR_INVALID_ARGUMENT;
   ctx->timing = enable != 0;
   ctx->ev_valid_br = ctx->ev_valid_ks = false;
+  ctx->timed_bootstraps = 0;
   return TFHE_OK;
 }
 
@@ -545,6 +560,20 @@ int tfhe_measure_hbm_copy(tfhe_context* ctx, size_t bytes, int reps, double* gb_
   if (dst) (void)hipFree(dst);
   if (e != hipSuccess) return hip_fail(ctx, e, "hbm copy probe");
   *gb_per_s = 2.0 * (double)bytes * reps / ((double)ms * 1e-3) / 1e9;  // read + write
+  return TFHE_OK;
+}
+
+int tfhe_kernel_ms_ago(tfhe_context* ctx, unsigned steps_ago, float* blind_rotate_ms, float* key_switch_ms) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  if (!blind_rotate_ms || !key_switch_ms) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer");
+  if (steps_ago >= (unsigned)tfhe_context::kTimingSlots || (unsigned long long)steps_ago >= ctx->timed_bootstraps)
+    return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "no timed bootstrap that far back");
+  hipEvent_t* ev = ctx->ev_ring[(ctx->ev_slot + tfhe_context::kTimingSlots - (int)steps_ago) % tfhe_context::kTimingSlots];
+  HIP_TRY(ctx, hipEventSynchronize(ev[1]));
+  HIP_TRY(ctx, hipEventElapsedTime(blind_rotate_ms, ev[0], ev[1]));
+  HIP_TRY(ctx, hipEventSynchronize(ev[3]));
+  HIP_TRY(ctx, hipEventElapsedTime(key_switch_ms, ev[2], ev[3]));
   return TFHE_OK;
 }
 

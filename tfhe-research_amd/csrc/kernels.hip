@@ -691,14 +691,18 @@ hipError_t allow_lds(Kern kern, size_t bytes, std::atomic<unsigned long long>& d
   return e;
 }
 
-// samples per blind-rotation launch (TFHE_BR_CHUNK overrides the default for experiments)
+// samples per blind-rotation launch: 4,096 for the complex transform, whose kernel lives on an L2-hot key; the
+// prime-field kernels are VALU bound and lose 2.5 % to the launch boundaries (cfg3, 65,536 gates: 48.8 k against
+// 49.9 k gates/s), so they only split beyond 2^20 (the grid is a 32-bit number).  TFHE_BR_CHUNK overrides both.
+template <class F>
 inline size_t blind_rotate_chunk() {
-  static const size_t chunk = [] {
+  static const size_t env_chunk = [] {
     const char* env = std::getenv("TFHE_BR_CHUNK");
     const long v = env ? std::atol(env) : 0;
-    return v > 0 ? (size_t)v : (size_t)4096;
+    return v > 0 ? (size_t)v : (size_t)0;
   }();
-  return chunk;
+  if (env_chunk) return env_chunk;
+  return F::kLogShrink ? (size_t)4096 : ((size_t)1 << 20);
 }
 
 template <class F, int LOGN, int K>
@@ -715,13 +719,13 @@ hipError_t launch_blind_rotate(hipStream_t s, const PbsParams& P, const void* tw
     static std::atomic<unsigned long long> lds_done{0};
     hipError_t e = allow_lds(kern, C::kLds, lds_done);
     if (e != hipSuccess) return e;
-    // Long batches go out in launches of blind_rotate_chunk() samples.  All teams of a launch walk the key in
+    // Long batches go out in launches of blind_rotate_chunk<F>() samples.  All teams of a launch walk the key in
     // step (GGSW_i is read by every team at about the same time and stays hot in the L2s); in ONE launch of
     // 131,072 samples the dispatcher refills finished teams one by one, after a few thousand samples every
     // iteration of the key is in use somewhere and the 124 MB key streams from the Infinity Cache instead:
     // the complex-FFT kernel, which needs 13 TB/s of key, ran 75.0 k PBS/s that way against 108.9 k at 4,096
     // (profiles/r02_f_*).  Launches on one stream run back to back.
-    const size_t chunk = blind_rotate_chunk();
+    const size_t chunk = blind_rotate_chunk<F>();
     for (size_t off = 0; off < batch; off += chunk) {
       const size_t here = batch - off < chunk ? batch - off : chunk;
       hipLaunchKernelGGL(kern, dim3((unsigned)here), dim3(C::kThreads), C::kLds, s, P, tw,
