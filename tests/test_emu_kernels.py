@@ -258,6 +258,8 @@ def test_external_product_worst_case_magnitudes(emu, oracle, field, k, logn, pbs
     N = params.N
     if not field_exact(field, k, logn, pbs, g):
         pytest.skip("outside this field's exactness bound: the context selects another field here")
+    if field == FFT and logn == 11 and g != 4:
+        pytest.skip("the complex transform at N = 2048 (not shipped on the GPU) keeps its five-pass shape only: run time")
     first_shift = log_base * (32 // log_base - levels)
     # word whose every kept limb is B-1 with an incoming carry -> digits B ... (top ones), built by brute force
     def word_with_digits(target):
