@@ -669,3 +669,29 @@ def test_backends_agree_at_full_size_cfg2_with_a_key_dependent_rotation(oracle):
         orc_mode.set_poly_mul_mode(1)
         for b in range(3):
             assert np.array_equal(host[b], orc_mode.bootstrap(p, rows[b], bsk, ksk, tv)), b
+
+
+def test_timing_ring_reads_back_every_step_of_a_loop(oracle):
+    """tfhe_kernel_ms_ago: K bootstraps enqueued back to back with timing on, their kernel durations read afterwards
+    (no host synchronisation inside the loop); asking further back than what was timed is refused."""
+    import torch
+    m = pkg()
+    p = oracle.CFG1
+    _, bsk, ksk, tv = oracle.synthetic_inputs(p, 1, cfg_index=1)
+    lwe = torch.randint(-(1 << 31), (1 << 31) - 1, (64, p.n + 1), dtype=torch.int32, device="cuda:0")
+    tv_d = torch.from_numpy(tv.view(np.int32)).to("cuda:0")
+    with m.Context(to_pkg_params(p)) as ctx:
+        ctx.load_bootstrapping_key(bsk, ksk)
+        ctx.use_torch_stream()
+        ctx.set_timing(True)
+        out = torch.empty_like(lwe)
+        for _ in range(5):
+            ctx.bootstrap(lwe, tv_d, out=out)
+        times = [ctx.kernel_ms_ago(i) for i in range(5)]
+        assert all(br > 0 and ks > 0 for br, ks in times)
+        assert times[0] == ctx.last_kernel_ms()
+        with pytest.raises(m.TfheError) as e:
+            ctx.kernel_ms_ago(5)
+        assert e.value.status == m.TFHE_ERR_INVALID_ARGUMENT
+        torch.cuda.synchronize()
+        ctx.set_stream(None)
