@@ -176,3 +176,10 @@ fn golden_replay_misaligned_base() {
     // log_base = 7 does not divide 32: pins decomposer.rs:48-70 (limbs counted from bit 0)
     replay_set("misaligned");
 }
+
+#[test]
+fn golden_replay_n1024_full_word() {
+    // N = 1024 with l = 4 levels of 2^8: the whole word is decomposed, so (unlike the set above, whose trivial
+    // accumulator has only zero digits) every CMUX of this trace depends on the key
+    replay_set("n1024_full_word");
+}

@@ -14,7 +14,7 @@ import pytest
 import golden_common as gc
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SETS = ["ref_test", "misaligned"]
+SETS = ["ref_test", "misaligned", "n1024_full_word"]
 
 
 def test_fixture_files_are_well_formed():

@@ -10,7 +10,7 @@ from gpu_common import pkg
 
 pytestmark = pytest.mark.gpu
 
-SETS = ["ref_test", "misaligned"]
+SETS = ["ref_test", "misaligned", "n1024_full_word"]
 BACKENDS = ["auto", "fp64", "fp64-p49", "fp64-fft", "goldilocks", "goldilocks-split"]
 
 

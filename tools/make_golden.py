@@ -21,6 +21,7 @@ Sets (every array is one file in the library's on-disk format, include/tfhe_hip.
                KS l=5 logB=4) with REAL keys (oracle keygen, fixed seed): rows 0-3 encrypt the
                messages 0..3, rows 4-7 are edge cases (a~ = 0, b~ rounding to 2N, all words
                0x80000000, uniform words).  Identity test vector.
+  n1024_full_word/  N=1024, k=1, n=3, PBS l=4 logB=8 (the whole word decomposed: every CMUX depends on the key)
   misaligned/  N=1024, k=1, n=3, PBS l=3 logB=7 (the BASELINE cfg2 decomposer, log_base does not
                divide 32: decomposer.rs:48-70 counts limbs from bit 0), uniform synthetic words,
                a non-identity LUT.
@@ -85,6 +86,18 @@ def small_sets():
     lwe_in[2, :] = 0x80000000
     lwe_in[3, :] = 0xF8F8F8F8      # every limb at B-1 with a carry chain (digit == B path)
     out["misaligned"] = (p, dict(bsk=bsk, ksk=ksk, lwe_in=lwe_in, tv=tv))
+    # ---- N = 1024 with a decomposer that covers the whole word (l = 4, logB = 8): unlike the set above, whose
+    # digits of a trivial accumulator are all zero (bits 28..31 are never decomposed), every CMUX here depends on
+    # the key -- the frozen trace that pins the N = 1024 kernels (the complex-FFT backend's home) stage by stage
+    p = orc.Params(1, 10, 3, orc.Decomposer(8, 4))
+    lut = [1, 3, 0, 2]
+    lwe_in, bsk, ksk, tv = orc.synthetic_inputs(p, 8, cfg_index=0x601F, lut=lut)
+    lwe_in = lwe_in.copy()
+    lwe_in[0, 0] = 0
+    lwe_in[1, p.n] = 0xFFFFFFFF
+    lwe_in[2, :] = 0x80000000
+    lwe_in[3, :] = 0xFFFFFFFF      # every limb at B-1 with a carry chain
+    out["n1024_full_word"] = (p, dict(bsk=bsk, ksk=ksk, lwe_in=lwe_in, tv=tv))
     return out
 
 
