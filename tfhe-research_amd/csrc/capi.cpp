@@ -290,7 +290,7 @@ hipError_t upload_twiddles(tfhe_context* ctx) {
 
 extern "C" {
 
-const char* tfhe_version(void) { return "tfhe-research_amd 0.3 (gfx950; exact backends: fp64-fft, fp64-p49, fp64-p42, goldilocks, goldilocks-split)"; }
+const char* tfhe_version(void) { return "tfhe-research_amd 0.4 (gfx950; exact backends: fp64-fft, fp64-p49, fp64-p42, goldilocks, goldilocks-split)"; }
 
 const char* tfhe_status_string(int status) {
   switch (status) {
