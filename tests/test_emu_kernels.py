@@ -423,6 +423,17 @@ def test_glwe_mask_dot_key_vs_oracle(emu, oracle, field, k, logn, g):
             assert np.array_equal(dec[r], oracle.decrypt_glwe_raw(params, sk, expect[r]))
 
 
+def test_complex_transform_lds_layouts_in_the_bank_model():
+    """tools/ntt_model.py::conflicts_b128: the swizzles wave_ntt.h uses for 16-byte elements under gfx950's banking
+    of ds_read_b128 / ds_write_b128: N = 1024 (512 points) conflict free in every window; N = 512 (256 points) and
+    N = 2048 over four waves conflict free except two-way on the last window's stores"""
+    assert all(v == (0, 0) for v in ntt_model.conflicts_b128(9).values())
+    c8 = ntt_model.conflicts_b128(8)
+    assert all(v == (0, 0) for lo, v in c8.items() if lo != 0) and c8[0][0] == 0 and c8[0][1] <= 32
+    c10 = ntt_model.conflicts_b128(10, 4)
+    assert all(v == (0, 0) for lo, v in c10.items() if lo != 0) and c10[0][0] == 0 and c10[0][1] <= 4 * 32
+
+
 def test_key_word_split_has_no_signed_overflow(emu):
     """w = 0x7FFFxxxx with a negative low half: hi must come out as -32768 (w - lo = 2^31 taken in
     wrapping u32), found by the sanitizer run below."""
