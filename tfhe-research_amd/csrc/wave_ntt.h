@@ -465,7 +465,8 @@ TFHE_HD void ntt_pass_inverse(const Ctx& c, typename F::elem (&x)[NttShape<LOGN,
       const elem w = TOP ? top.tw(F::inverse_twiddle_index(h, r0 >> (rb + 1)))
                      : ntt_twiddles_transposed<(int)sizeof(elem)>() ? (F::kLogShrink ? tw[h + (r0 >> (rb + 1)) * H + hi]  // node h + hi cnt + i
                                                            : tw[h + (cnt - 1 - (r0 >> (rb + 1))) * H + (H - 1 - hi)])
-                                          : tw[F::inverse_twiddle_index(h, (hi << (LO + e - b - 1)) + (r0 >> (rb + 1)))];
+                                          : (F::kLogShrink ? tw[h + (hi << (LO + e - b - 1)) + (r0 >> (rb + 1))]
+                                                           : tw[2 * h - 1 - (hi << (LO + e - b - 1)) - (r0 >> (rb + 1))]);
       const elem u = x[r0];
       const elem v = x[r1];
       x[r0] = F::add(u, v);
