@@ -115,13 +115,17 @@ struct Monomial {
 // The GPU context: owns the device-side (NTT-domain) copy of one BootstrappingKey.
 class Engine {
  public:
-  explicit Engine(const TfheParams& params, int device = 0) : params_(params) {
+  // backend: TFHE_BACKEND_AUTO, or one of the transforms of tfhe_hip.h (every one returns the same bits;
+  // TFHE_ERR_EXACTNESS / TFHE_ERR_UNSUPPORTED if the parameter set is outside the chosen one's bound or shapes)
+  explicit Engine(const TfheParams& params, int device = 0, int backend = TFHE_BACKEND_AUTO) : params_(params) {
     tfhe_params cp = params.c();
     tfhe_context* raw = nullptr;
-    int st = tfhe_context_create(&cp, device, &raw);
+    int st = tfhe_context_create_with_backend(&cp, device, backend, &raw);
     if (st != TFHE_OK) throw TfheError(st, std::string("tfhe_context_create: ") + tfhe_status_string(st));
     ctx_.reset(raw);
   }
+  // "fp64-fft", "fp64-p49", "fp64-p42", "goldilocks" or "goldilocks-split"
+  std::string backend() const { return tfhe_context_backend(ctx_.get()); }
 
   // Uploads the key in the reference's own layout (n separate GGSW arrays + the KSK array).  A key of
   // the unrolled blind rotation (notes/BMMP Bootstrapping.md; bootstrapping_key_gen_bmmp below) holds
