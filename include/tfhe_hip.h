@@ -84,7 +84,7 @@ int tfhe_params_validate(const tfhe_params *params);
  *   GOLDILOCKS p = 2^64 - 2^32 + 1, u64 arithmetic; needs (k+1)*l * N * B * 2^32 < 2^62
  *   GOLDILOCKS_SPLIT  the same field with the key split into 16-bit halves; needs
  *              (k+1)*l * N * B * 2^15 < 2^62, which every base the reference can express satisfies
- *   AUTO       the first of FP64_FFT (below; not at N = 512 where FP64_P49 is exact), FP64_P49, FP64, GOLDILOCKS,
+ *   AUTO       the first of FP64_FFT (below; not where FP64_P49 is exact and (k+1)*l > 8), FP64_P49, FP64, GOLDILOCKS,
  *              GOLDILOCKS_SPLIT whose bound holds
  *              (env TFHE_HIP_BACKEND=fp64-fft|fp64-p49|fp64|goldilocks|goldilocks-split overrides AUTO). */
 #define TFHE_BACKEND_AUTO 0

@@ -364,11 +364,13 @@ int tfhe_context_create_with_backend(const tfhe_params* params, int device, int 
     else if (env && std::strcmp(env, "goldilocks-split") == 0) backend = TFHE_BACKEND_GOLDILOCKS_SPLIT;
     else if (env && std::strcmp(env, "fp64-fft") == 0) backend = TFHE_BACKEND_FP64_FFT;
   }
-  // AUTO: the complex transform first, except where the single-spectrum 49-bit field is exact at N = 512: with
-  // many digit rows the key stream decides, and fp64-fft's two spectra per key polynomial make it twice as
-  // long (the reference's default parameters: 145.7 ms against 77 ms per 4096 bootstraps)
+  // AUTO: the complex transform first, except where the single-spectrum 49-bit field is exact and the product has
+  // many digit rows: then the key stream decides, and fp64-fft's two spectra per key polynomial make it twice as
+  // long (per 4096 bootstraps: the reference's default parameters, 18 rows: 145.7 ms against 77 ms; N = 1024, k = 1,
+  // l = 10, 20 rows: 150.7 against 125.2 ms; N = 512, k = 1, l = 4, 8 rows: 25.4 against 26.0 ms -- there it wins)
+  const uint32_t digit_rows = (params->glwe_dimension + 1) * params->pbs_decomposer.levels;
   if (backend == TFHE_BACKEND_AUTO)
-    field = (fft_ok && !(params->glwe_poly_degree == 9 && fp49_ok)) ? launch::kFieldFft
+    field = (fft_ok && !(fp49_ok && digit_rows > 8)) ? launch::kFieldFft
             : fp49_ok ? launch::kFieldFp49
             : fp_ok ? launch::kFieldFp64
             : gl_ok ? launch::kFieldGoldilocks
