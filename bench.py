@@ -70,20 +70,40 @@ def measure_hbm_copy_gbs(torch, dev, mib: int = 1024, reps: int = 10, ctx=None) 
         return HBM_MEASURED_GBS
 
 
+def kernel_source_hash() -> str:
+    """sha256 over the sources the device code is built from (csrc/*, include/tfhe_hip.h, the build recipe), first
+    16 hex digits: identifies the kernels a PMC record was measured on.  (Not the .so itself: hipcc output embeds
+    build paths, and the box that collects counters builds nothing -- it runs the library this tree built.)"""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "tfhe-research_amd", "csrc")
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc))
+    files += [os.path.join(ROOT, "include", "tfhe_hip.h"), os.path.join(ROOT, "tfhe-research_amd", "build.py")]
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel: str, workload: str, batch: int):
     """HBM/fabric bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
     (FETCH_SIZE and WRITE_SIZE are collected in separate runs; FETCH_SIZE doubled per the gfx950
     correction).  Counters cannot be collected inside this process, so the number is only reported
-    when the committed measurement is for this very kernel and workload."""
+    when the committed measurement is for this very kernel and workload AND was taken on the kernels this
+    tree builds (`kernel_source_hash`): a record of an older kernel is refused, not silently reused."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
             rec = json.load(f)
     except (OSError, ValueError):
         return None, None, None
-    if rec.get("kernel") == kernel and rec.get("workload") == f"{workload} batch {batch}":
-        return rec["traffic_bytes_per_launch"], rec.get("source"), rec.get("valu") or None
-    return None, None, None
+    if rec.get("kernel") != kernel or rec.get("workload") != f"{workload} batch {batch}":
+        return None, None, None
+    if rec.get("kernel_source_hash") != kernel_source_hash():
+        return None, (f"profiles/pmc_traffic.json is stale: measured on kernel sources {rec.get('kernel_source_hash')}, "
+                      f"this tree is {kernel_source_hash()} (redo tools/final_profile.sh)"), None
+    return rec["traffic_bytes_per_launch"], rec.get("source"), rec.get("valu") or None
 
 WORKLOADS = {
     # name: (k, logN, n, (pbs logB, l), (ks logB, l), log_p, default batch)
@@ -95,7 +115,7 @@ WORKLOADS = {
     "cfg4": (1, 10, 630, (7, 3), (4, 5), 2, 1 << 17),
 }
 CPU_BASELINE_PBS = 3        # >= 3 PBS on one thread (the reference is single-threaded)
-CPU_BASELINE_THREADS = 16   # the all-cores leg: one round of independent ciphertexts, capped
+CPU_BASELINE_THREADS = 16   # the multi-thread leg: one round of independent ciphertexts on 16 threads (NOT all cores)
 
 
 def cpu_baseline(workload: str, budget_s: float):
@@ -133,8 +153,9 @@ def cpu_baseline(workload: str, budget_s: float):
         with ThreadPoolExecutor(threads) as pool:
             list(pool.map(lambda row: orc.bootstrap(p, row, bsk, ksk, tv), lwe_many))
         dt_all = time.perf_counter() - t1
-        result["all_cores"] = {"value": threads / dt_all, "unit": "PBS/s", "cores": threads,
-                               "sample": f"{threads} bootstraps on {threads} threads in {dt_all:.1f} s"}
+        result[f"cores_{threads}"] = {"value": threads / dt_all, "unit": "PBS/s", "cores": threads,
+                                      "sample": f"{threads} bootstraps on {threads} threads in {dt_all:.1f} s "
+                                                f"(a capped leg: the host has {os.cpu_count()} cores)"}
     orc.set_poly_mul_mode(1)
     return result
 
@@ -201,6 +222,11 @@ def bench_external_product(args, pkg, params, batch, dev, rand_words, world, ran
     algo = batch * params.external_product_bytes()
     physical = (count * prepared.shape[1] * 8) + 2 * batch * (params.k + 1) * params.N * 4
     achieved = algo / (kernel_ms * 1e-3) / 1e9
+    # with ONE GGSW shared by the batch a product only moves its GLWE in and out -- 8 N (k+1) bytes --
+    # and the GGSW once per launch; that accounting is reported beside the 4 N (k+1) ((k+1) l + 2) one, labelled
+    glwe_only = 8 * params.N * (params.k + 1)
+    algo_shared = batch * glwe_only + params.R * (params.k + 1) * params.N * 4
+    achieved_shared = algo_shared / (kernel_ms * 1e-3) / 1e9
     hbm_copy = measure_hbm_copy_gbs(torch, dev, ctx=ctx)
     result = {
         "metric": "external_products_per_sec", "value": batch * world * steps / dt, "unit": "products/s",
@@ -218,6 +244,15 @@ def bench_external_product(args, pkg, params, batch, dev, rand_words, world, ran
                      "physical_operand_bytes_per_launch": physical,
                      "physical_GBps": physical / (kernel_ms * 1e-3) / 1e9},
     }
+    if not args.ggsw_per_sample:
+        result["roofline"].update({
+            "accounting": "achieved/frac price every product at 4N(k+1)((k+1)l+2) bytes (GGSW + GLWE in + GLWE out, SURVEY 8d's "
+                          "unit) although this launch reads ONE GGSW for the whole batch; achieved_shared_ggsw prices what "
+                          "the shape really moves: 8N(k+1) bytes per product + the GGSW once",
+            "achieved_shared_ggsw": achieved_shared, "frac_shared_ggsw": achieved_shared / HBM_PEAK_GBS,
+            "frac_of_measured_hbm_shared_ggsw": achieved_shared / hbm_copy,
+            "algorithmic_bytes_per_launch_shared_ggsw": algo_shared,
+            "bound": "valu-issue (the operands are L2-resident; neither accounting comes near HBM)"})
     if raw_ms is not None:
         raw_bytes = count * params.R * (params.k + 1) * params.N * 4 + 2 * batch * (params.k + 1) * params.N * 4
         result["raw_u32_ggsw"] = {
@@ -415,7 +450,10 @@ def main():
         },
         "roofline": {
             "kernel": kernel_name,
-            "bound": "hbm",
+            # what binds the kernel (PMC: counter traffic is a tenth of the algorithmic bytes); achieved/peak/frac
+            # stay priced against the HBM roofline, which is the metric BASELINE.json asks for
+            "bound": "valu-issue",
+            "priced_against": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -458,6 +496,33 @@ def main():
             "ms_per_step": float(t_sg.item()) / sg_steps * 1e3,
             "what": f"rank 0 holds all {batch * world} ciphertexts: isend/recv scatter of {batch * (n + 1) * 4 / 1e6:.0f} MB per peer "
                     "over RCCL/xGMI, local bootstrap, gather back; NOT the headline value"}
+    if not args.gate and not args.scatter_gather and pbs[0] * (32 // pbs[0]) != 32:
+        # log2 B does not divide 32 (cfg2: 7): with the reference's literal decomposer the top 32 mod log2 B bits of a
+        # word are never decomposed, a trivially encrypted accumulator has no bit below them, every digit is zero and
+        # the blind rotation never depends on the key -- in the reference too (decomposer.rs:42-80).  The
+        # timed region above therefore multiplies zeros.  The kernels have no data-dependent branch; this leg puts
+        # that on record: the same step with the aligned decomposer, where every CMUX depends on key and data.
+        try:
+            ctx.set_decomposer_alignment(True)
+            ctx.bootstrap(lwe, tv, out=out)
+            barrier()
+            t_al = time.perf_counter()
+            for _ in range(3):
+                ctx.bootstrap(lwe, tv, out=out)
+            barrier()
+            dt_al = time.perf_counter() - t_al
+            distinct = int(torch.unique(out[:256]).numel())
+            result["aligned_decomposer"] = {
+                "kernel_ms": float(np.mean([ctx.kernel_ms_ago(i)[0] for i in range(3)])),
+                "value": batch * 3 / dt_al, "unit": "PBS/s", "steps": 3,
+                "literal_kernel_ms": br_avg,
+                "distinct_output_words_in_256_rows": distinct,
+                "what": "same step, tfhe_context_set_decomposer_alignment(1): digits are non-zero and the rotation depends on "
+                        "the key (the literal cfg2 decomposer yields all-zero digits, in the reference as well); the kernels "
+                        "have no data-dependent branch, so the two times agree"}
+            ctx.set_decomposer_alignment(False)
+        except Exception as e:  # noqa: BLE001 - a secondary figure must not lose the benchmark line
+            result["aligned_decomposer"] = {"error": str(e)}
     ctx.close()
     if world == 1 and backend_name == "fp64-fft" and not args.gate and args.backend == "auto":
         # beside the headline (never instead of it): the same step in the exact prime-field NTT the complex-FFT backend

@@ -94,8 +94,8 @@ int tfhe_params_validate(const tfhe_params *params);
 #define TFHE_BACKEND_FP64_P49 4
 /* FP64_FFT: the negacyclic product through a complex FFT in fp64 (N/2 points, two coefficients per element,
  *            key split into 16-bit halves), exact by a proven bound on the rounding error of every output
- *            coefficient (csrc/field_fft.h: 3.1 n eta R M^1.5 |x| |y| < 1/4, e.g. 0.011 at N = 1024, k = 1,
- *            l = 3, log_base = 7); kernels at N = 512 and 1024.  Same bits as the exact-NTT fields. */
+ *            coefficient (csrc/field_fft.h: (3 n eta + sqrt 2 (R + 1) u) R M^1.5 |x| |y| < 1/4, e.g. 0.013 at N = 1024,
+ *            k = 1, l = 3, log_base = 7); kernels at N = 512 and 1024.  Same bits as the exact-NTT fields. */
 #define TFHE_BACKEND_FP64_FFT 5
 
 /* Creates a context bound to HIP device `device`.  Fails with TFHE_ERR_NO_DEVICE when no GPU is
@@ -356,6 +356,13 @@ int tfhe_kernel_ms_ago(tfhe_context *ctx, unsigned steps_ago, float *blind_rotat
  * buffers are allocated and freed inside), `reps` timed launches on the context's stream;
  * *gb_per_s = (bytes read + bytes written) / time.  Synchronises. */
 int tfhe_measure_hbm_copy(tfhe_context *ctx, size_t bytes, int reps, double *gb_per_s);
+
+/* Rounding-margin probe of the FP64_FFT backend (test instrumentation, not a reference function): the largest
+ * |value - nearest integer| any lane has lifted on the device since the last reset -- the measured counterpart of
+ * the proven bound in csrc/field_fft.h.  Only the probe build (libtfhe_hip_probe.so, -DTFHE_FFT_TRACK_ERROR; kept
+ * beside the product library, never loaded by it) records it; the product library returns TFHE_ERR_UNSUPPORTED.
+ * Synchronises the device. */
+int tfhe_debug_fft_margin(tfhe_context *ctx, double *worst, int reset);
 
 /* Library / build identification */
 const char *tfhe_version(void);

@@ -31,7 +31,40 @@ def fft_error_bound(logn, rows, log_base):
     import math
     u = 2.0 ** -53
     m, n = float(1 << (logn - 1)), float(logn - 1)
-    return 3.1 * n * 7.1 * u * rows * m * math.sqrt(m) * math.sqrt(2) * (1 << log_base) * math.sqrt(2) * 32768.0
+    # three transforms of n stages (eta = 7.1 u each) + the FMA chain accumulating `rows` products (quadratic in rows)
+    per_unit = 1.001 * (3.0 * n * 7.1 * u + 1.42 * (rows + 1.0) * u)
+    return per_unit * rows * m * math.sqrt(m) * math.sqrt(2) * (1 << log_base) * math.sqrt(2) * 32768.0
+
+
+# the parameter sets with the largest proven bound below 1/4 that AUTO gives to fp64-fft (no prime field admits
+# log2 B > 9 and the 49-bit one stops at N B rows < 2^17.25): N = 1024, k = 2, l = 2, B = 2^11 (0.209) and
+# N = 512, k = 1, l = 2, B = 2^13 (0.174); next to them N = 1024, k = 2, l = 3, B = 2^10 (0.160)
+FFT_EDGE_SHAPES = [(2, 10, (11, 2), 1), (1, 9, (13, 2), 1), (2, 10, (10, 3), 1)]
+
+
+def extreme_operands(oracle, params, pbs, rng, random_signs):
+    """GGSW and GLWE at the magnitude bound of the exactness argument: every digit +B or -B/2, every signed 16-bit
+    key half at +-2^15.  random_signs=False: constant polynomials with the negacyclic sign pattern that makes all N
+    terms of coefficient 0 add up (maximal |z|).  random_signs=True: the same magnitudes with an independent random
+    choice per coefficient -- the adversarial case for the FFT's ROUNDING error, which a constant polynomial (one
+    non-zero spectral pattern) does not exercise."""
+    k, N = params.k, params.N
+    cand = np.concatenate([rng.integers(0, 1 << 32, size=200000, dtype=np.uint64).astype(np.uint32),
+                           np.array([0xFFFFFFFF, 0x7FFFFFFF, 0xF8F8F8F8, 0xFFFFFF80, 0x80000000], dtype=np.uint32)])
+    score = oracle.decompose(oracle.Decomposer(*pbs), cand).astype(np.int32).astype(np.int64).sum(axis=1)
+    wpos, wneg = cand[int(score.argmax())], cand[int(score.argmin())]
+    key_words = np.array([0x7FFF7FFF, 0x80008000, 0x7FFF8000, 0x80007FFF], dtype=np.uint32)  # halves (+,+) (-,-) (-,-) (+,-)
+    if random_signs:
+        ggsw = rng.choice(key_words, size=(params.R, k + 1, N))
+        glwe = rng.choice(np.array([wpos, wneg], dtype=np.uint32), size=(k + 1, N))
+        return [(ggsw, glwe)]
+    out = []
+    for kw in key_words[:3]:
+        for gw in (wpos, wneg):
+            ggsw = np.full((params.R, k + 1, N), kw, dtype=np.uint32)
+            ggsw[:, :, 1:] = (np.uint32(0) - ggsw[:, :, 1:]).astype(np.uint32)
+            out.append((ggsw, np.full((k + 1, N), gw, dtype=np.uint32)))
+    return out
 
 
 def field_exact(field, k, logn, pbs, g=1):
@@ -248,7 +281,7 @@ def test_external_product_vs_oracle(emu, oracle, exchange_buffers, field, k, log
 
 @pytest.mark.parametrize("field", FIELDS)
 @pytest.mark.parametrize("k,logn,pbs,g", [(1, 10, (7, 3), 1), (2, 11, (8, 4), 2), (2, 11, (8, 4), 4), (2, 9, (4, 6), 1), (1, 9, (16, 2), 1),
-                                          (1, 10, (2, 10), 1), (2, 11, (2, 5), 4)])
+                                          (1, 10, (2, 10), 1), (2, 11, (2, 5), 4)] + FFT_EDGE_SHAPES)
 def test_external_product_worst_case_magnitudes(emu, oracle, field, k, logn, pbs, g):
     """Adversarial inputs that drive the integer convolution to its bound: every digit at +B or
     -B/2 and every key word at 0x7FFF8000-type extremes (both 16-bit halves maximal), aligned so
@@ -285,12 +318,13 @@ def test_external_product_worst_case_magnitudes(emu, oracle, field, k, logn, pbs
         assert np.array_equal(out, oracle.external_product(params, ggsw, glwe)), hex(key_word)
 
 
-@pytest.mark.parametrize("k,logn,pbs,g", [(1, 10, (7, 3), 1), (1, 9, (8, 2), 1), (2, 9, (4, 6), 1), (2, 11, (8, 4), 2)])
+@pytest.mark.parametrize("k,logn,pbs,g", [(1, 10, (7, 3), 1), (1, 9, (8, 2), 1), (2, 9, (4, 6), 1), (2, 11, (8, 4), 2)] + FFT_EDGE_SHAPES)
 def test_fft_rounding_margin(emu, oracle, k, logn, pbs, g):
     """The complex-FFT backend is exact because every lifted value is within 1/2 of the integer it stands for.
     field_fft.h proves a bound (FftField::error_bound, admitted below 1/4); this measures the distance the emulator
-    actually sees -- on operands at the magnitude bound and on random ones -- and holds it against that bound, and
-    the Python restatement of the bound against the C++ one."""
+    actually sees -- on operands at the magnitude bound (constant-sign AND random-sign ones) and on random ones -- and
+    holds it against that bound, and the Python restatement of the bound against the C++ one.  The shapes include the
+    admission edge: the parameter sets with the largest bound below 1/4 that AUTO hands to this backend."""
     emu.emu_fft_error_bound.restype = C.c_double
     emu.emu_fft_error_max.restype = C.c_double
     log_base, levels = pbs
@@ -301,19 +335,14 @@ def test_fft_rounding_margin(emu, oracle, k, logn, pbs, g):
     params = oracle.Params(k, logn, 1, oracle.Decomposer(*pbs))
     N = params.N
     rng = np.random.default_rng(logn + 7 * k)
-    cand = rng.integers(0, 1 << 32, size=100000, dtype=np.uint64).astype(np.uint32)
-    d = oracle.decompose(oracle.Decomposer(*pbs), cand).astype(np.int32).astype(np.int64).sum(axis=1)
-    wpos, wneg = int(cand[int(d.argmax())]), int(cand[int(d.argmin())])
     worst = 0.0
-    cases = [(kw, gw) for kw in (0x7FFF7FFF, 0x80008000, 0x7FFF8000) for gw in (wpos, wneg)] + [(None, None)] * 2
-    for key_word, glwe_word in cases:
-        if key_word is None:
-            ggsw = rng.integers(0, 1 << 32, size=(params.R, k + 1, N), dtype=np.uint64).astype(np.uint32)
-            glwe = rng.integers(0, 1 << 32, size=(k + 1, N), dtype=np.uint64).astype(np.uint32)
-        else:
-            ggsw = np.full((params.R, k + 1, N), key_word, dtype=np.uint32)
-            ggsw[:, :, 1:] = (np.uint32(0) - ggsw[:, :, 1:]).astype(np.uint32)
-            glwe = np.full((k + 1, N), glwe_word, dtype=np.uint32)
+    cases = extreme_operands(oracle, params, pbs, rng, False)
+    for _ in range(4):
+        cases += extreme_operands(oracle, params, pbs, rng, True)
+    for _ in range(2):
+        cases.append((rng.integers(0, 1 << 32, size=(params.R, k + 1, N), dtype=np.uint64).astype(np.uint32),
+                      rng.integers(0, 1 << 32, size=(k + 1, N), dtype=np.uint64).astype(np.uint32)))
+    for ggsw, glwe in cases:
         spec = prepared(emu, FFT, params, ggsw, g)
         out = np.zeros_like(glwe)
         emu.emu_fft_error_reset()
@@ -323,6 +352,17 @@ def test_fft_rounding_margin(emu, oracle, k, logn, pbs, g):
     # measured distance from the integers: orders of magnitude inside the proven bound, itself inside 1/4
     assert worst < bound / 100, (worst, bound)
     print(f"fft rounding margin N=2^{logn} k={k} rows={rows} B=2^{log_base}: measured {worst:.3g}, proven bound {bound:.3g}")
+
+
+def test_fft_error_bound_is_quadratic_in_the_rows():
+    """The accumulation term of the bound: R products summed by an FMA chain round the running sum R times, so the
+    rounding part grows like R (R + 1), not like R.  Pinned numbers of the corrected formula."""
+    assert abs(fft_error_bound(10, 6, 7) - 0.013067) < 2e-6      # cfg2
+    assert abs(fft_error_bound(9, 18, 4) - 0.0016958) < 2e-7     # the reference's default parameters
+    assert abs(fft_error_bound(10, 6, 11) - 0.20907) < 2e-5      # the largest admitted set at N = 1024
+    assert fft_error_bound(10, 6, 12) > 0.25                     # one more bit of base: refused
+    r1, r2 = fft_error_bound(10, 10, 2), fft_error_bound(10, 20, 2)
+    assert r2 / r1 > 2.05                                        # more than linear in the rows
 
 
 @pytest.mark.parametrize("field", FIELDS)

@@ -340,6 +340,41 @@ def test_full_size_cfg3_nand_gate_stream(oracle):
         assert np.array_equal(out[i], oracle.boolean_gate(p, nand, ct0[i], ct1[i], bsk, ksk)), i
 
 
+def test_cfg3_nand_gate_stream_65536_scrambled_copies(oracle):
+    """BASELINE configs[2] as stated: a stream of 65,536 homomorphic NAND gates at the reference's default parameters
+    (boolean.rs:9-53, lib.rs:101-123) in ONE tfhe_gate_batch_device call with real keys.  The stream is assembled on the
+    device from 256 distinct encrypted input pairs in a scrambled order (as test_cfg4_per_gpu_share_scrambled_copies
+    does for cfg4): every one of the 65,536 outputs must equal the output of its source pair in the 256-gate run --
+    whichever workgroup, launch of the grid or key-switch tile it lands in -- and the 256-gate run itself decrypts to
+    NAND of its inputs and matches the oracle's boolean gate word for word on sampled gates."""
+    import torch
+    p = oracle.CFG3
+    rng = oracle.Rng(4242)
+    lwe_sk, glwe_sk, bsk, ksk = oracle.keygen(p, rng)
+    m = pkg()
+    dev = torch.device("cuda", 0)
+    distinct, stream = 256, 65536
+    bits = np.random.default_rng(19).integers(0, 2, size=(distinct, 2))
+    ct1 = np.stack([oracle.encrypt_lwe(p, lwe_sk, int(b[0]), rng) for b in bits])
+    ct0 = np.stack([oracle.encrypt_lwe(p, lwe_sk, int(b[1]), rng) for b in bits])
+    with m.Context(to_pkg_params(p)) as ctx:
+        ctx.load_bootstrapping_key(bsk, ksk)
+        base = ctx.gate(m.GATE_NAND, ct0, ct1)
+        order = torch.from_numpy(np.random.default_rng(23).integers(0, distinct, size=stream)).to(dev)
+        ct0_d = torch.from_numpy(ct0.view(np.int32)).to(dev).index_select(0, order).contiguous()
+        ct1_d = torch.from_numpy(ct1.view(np.int32)).to(dev).index_select(0, order).contiguous()
+        out_d = ctx.gate(m.GATE_NAND, ct0_d, ct1_d)
+        want_d = torch.from_numpy(base.view(np.int32)).to(dev).index_select(0, order)
+        assert tuple(out_d.shape) == (stream, p.n + 1)
+        assert torch.equal(out_d, want_d)
+        ctx.set_stream(None)
+    for i in range(distinct):
+        assert oracle.decrypt_lwe_message(p, lwe_sk, base[i]) == 1 - (bits[i, 0] & bits[i, 1]), i
+    nand = lambda l, r: 1 - (l & r)
+    for i in (0, 77, 255):
+        assert np.array_equal(base[i], oracle.boolean_gate(p, nand, ct0[i], ct1[i], bsk, ksk)), i
+
+
 def test_full_size_cfg1_and_cfg5_single_sample(oracle):
     """BASELINE cfg1 (N=512, k=1, n=500, l=2, logB=8) and cfg5 (N=2048, k=2, n=630, l=4, logB=8,
     log_p=4 LUT of 16 entries) at full size: one sample each against the oracle (cfg5 costs the
@@ -639,7 +674,8 @@ def test_backends_agree_at_full_size_cfg2_with_a_key_dependent_rotation(oracle):
     accumulator has no bit below 2^29 while bits 28..31 are never decomposed, so every digit is zero and the blind
     rotation ignores the key; aligned, all 630 CMUXes do real work.  4,096 random ciphertexts and a random
     key through the complex-FFT backend and the 42-bit prime field, the first 512 also through both Goldilocks fields:
-    every output word equal, and three rows against the oracle in the same mode."""
+    every output word equal, and 96 rows spread over the batch against the oracle in the same mode (host cores in
+    parallel) -- the full-size key-dependent cfg2 check against the CPU restatement itself, not only between backends."""
     import torch
     p = oracle.CFG2
     m = pkg()
@@ -662,13 +698,17 @@ def test_backends_agree_at_full_size_cfg2_with_a_key_dependent_rotation(oracle):
     assert torch.unique(outs["fft"]).numel() > 100000  # the rotation did depend on the data
     assert torch.equal(outs["fft"], outs["p42"])
     assert torch.equal(outs["fft"][:slow], outs["gl"]) and torch.equal(outs["fft"][:slow], outs["gls"])
-    host = outs["fft"][:3].cpu().numpy().view(np.uint32)
-    rows = lwe[:3].cpu().numpy().view(np.uint32)
-    with oracle.decomposer_aligned(True):
-        orc_mode = oracle
-        orc_mode.set_poly_mul_mode(1)
-        for b in range(3):
-            assert np.array_equal(host[b], orc_mode.bootstrap(p, rows[b], bsk, ksk, tv)), b
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    host = outs["fft"].cpu().numpy().view(np.uint32)
+    rows = lwe.cpu().numpy().view(np.uint32)
+    picks = sorted(set([0, 1, 2, count - 1] + list(np.random.default_rng(11).choice(count, size=92, replace=False))))
+    with oracle.decomposer_aligned(True):   # a process-wide switch the worker threads only read
+        oracle.set_poly_mul_mode(1)
+        with ThreadPoolExecutor(max(1, min(16, os.cpu_count() or 1))) as pool:
+            want = list(pool.map(lambda b: oracle.bootstrap(p, rows[b], bsk, ksk, tv), picks))
+    bad = [int(b) for b, w in zip(picks, want) if not np.array_equal(host[b], w)]
+    assert len(picks) >= 64 and not bad, f"rows {bad} differ from the aligned-mode oracle"
 
 
 def test_timing_ring_reads_back_every_step_of_a_loop(oracle):

@@ -26,6 +26,11 @@ SHAPES = [
     ("p49_rows20_n1024", 1, 10, (2, 10)),
     ("p49_n2048", 2, 11, (2, 5)),
     ("wide_base", 1, 9, (16, 2)),
+    # the admission edge of fp64-fft: the sets with the largest proven rounding bound below 1/4 that AUTO hands to it
+    # (no prime field admits log2 B > 9): 0.209, 0.174 and 0.160 (csrc/field_fft.h::error_bound)
+    ("fft_edge_n1024_k2_b11", 2, 10, (11, 2)),
+    ("fft_edge_n512_k1_b13", 1, 9, (13, 2)),
+    ("fft_edge_n1024_k2_b10_l3", 2, 10, (10, 3)),
 ]
 BACKENDS = ["fp64", "fp64-p49", "fp64-fft", "goldilocks", "goldilocks-split"]
 KEY_WORDS = [0x7FFF7FFF, 0x80008000, 0x7FFF8000, 0xFFFFFFFF, 0x80000000, 0x7FFFFFFF]
@@ -87,6 +92,57 @@ def test_external_product_at_the_exactness_bound(oracle, name, k, logn, pbs, bac
         assert np.array_equal(got[b], oracle.external_product(p, ggsw[b], glwe[b])), (name, backend, b)
     for b in (0, 1):
         assert np.array_equal(shared[b], oracle.external_product(p, ggsw[0], glwe[b])), (name, backend, b)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("name,k,logn,pbs", SHAPES, ids=[s[0] for s in SHAPES])
+def test_external_product_at_the_bound_with_random_signs(oracle, name, k, logn, pbs, backend):
+    """The same magnitudes -- every digit +B or -B/2, every signed 16-bit key half +-2^15 -- with an independent
+    random choice per coefficient.  Constant polynomials maximise |z| (the exact fields' bound); for the complex
+    transform's ROUNDING error the adversarial operands are dense ones with full-magnitude spectra everywhere, which
+    random signs give.  32 products per shape: 8 of them against the oracle word for word, all 32 against the
+    Goldilocks-split backend (exact integer arithmetic, lifts every base the reference can express), and the
+    shared-GGSW launch shape against the per-sample one."""
+    p, ctx = open_context(oracle, k, logn, pbs, backend)
+    wpos, wneg = extreme_words(oracle, pbs)
+    N = p.N
+    rng = np.random.default_rng(logn * 131 + k * 17 + pbs[0])
+    key_words = np.array([0x7FFF7FFF, 0x80008000, 0x7FFF8000, 0x80007FFF], dtype=np.uint32)
+    batch = 32
+    ggsw = rng.choice(key_words, size=(batch, p.R, k + 1, N))
+    glwe = rng.choice(np.array([wpos, wneg], dtype=np.uint32), size=(batch, k + 1, N))
+    with ctx:
+        got = ctx.external_product(ggsw, glwe)
+        shared = ctx.external_product(ggsw[0], glwe)
+        aut = None
+        if ctx.backend() != "goldilocks-split":
+            # an independent exact route for the rows the oracle does not redo: Goldilocks-split lifts every base
+            m = pkg()
+            with m.Context(to_pkg_params(p), backend=m.BACKEND_GOLDILOCKS_SPLIT) as ref:
+                aut = ref.external_product(ggsw, glwe)
+    for b in range(8):
+        assert np.array_equal(got[b], oracle.external_product(p, ggsw[b], glwe[b])), (name, backend, b)
+    assert np.array_equal(shared[0], got[0]), (name, backend)
+    assert np.array_equal(shared[1], oracle.external_product(p, ggsw[0], glwe[1])), (name, backend)
+    if aut is not None:
+        assert np.array_equal(got, aut), (name, backend)
+
+
+def test_auto_picks_fft_at_the_admission_edge(oracle):
+    """AUTO hands the edge sets to fp64-fft (the proof carries the weight there), and refuses one more bit of base"""
+    m = pkg()
+    for name, k, logn, pbs in SHAPES:
+        if not name.startswith("fft_edge"):
+            continue
+        p = oracle.Params(k, logn, 4, oracle.Decomposer(*pbs))
+        with m.Context(to_pkg_params(p)) as ctx:
+            assert ctx.backend() == "fp64-fft", (name, ctx.backend())
+    p = oracle.Params(2, 10, 4, oracle.Decomposer(12, 2))
+    with pytest.raises(m.TfheError) as e:
+        m.Context(to_pkg_params(p), backend=m.BACKEND_FP64_FFT)
+    assert e.value.status == m.TFHE_ERR_EXACTNESS
+    with m.Context(to_pkg_params(p)) as ctx:     # AUTO falls through to an exact field that lifts it
+        assert ctx.backend() in ("goldilocks", "goldilocks-split")
 
 
 @pytest.mark.parametrize("backend", BACKENDS)

@@ -407,6 +407,14 @@ class Context:
         self._check(lib().tfhe_measure_hbm_copy(self._h, C.c_size_t(mib << 20), C.c_int(reps), C.byref(out)))
         return out.value
 
+    def fft_margin(self, reset: bool = True) -> float:
+        """largest |value - nearest integer| the fp64-fft kernels have lifted since the last reset; only the probe
+        build (libtfhe_hip_probe.so via TFHE_HIP_LIB, test instrumentation) records it -- the product library raises
+        TFHE_ERR_UNSUPPORTED"""
+        out = C.c_double()
+        self._check(lib().tfhe_debug_fft_margin(self._h, C.byref(out), C.c_int(int(reset))))
+        return out.value
+
     def last_kernel_ms(self):
         br, ks = C.c_float(), C.c_float()
         self._check(lib().tfhe_last_kernel_ms(self._h, C.byref(br), C.byref(ks)))

@@ -565,6 +565,19 @@ int tfhe_measure_hbm_copy(tfhe_context* ctx, size_t bytes, int reps, double* gb_
   return TFHE_OK;
 }
 
+int tfhe_debug_fft_margin(tfhe_context* ctx, double* worst, int reset) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+#if defined(TFHE_FFT_TRACK_ERROR)
+  HIP_TRY(ctx, launch::fft_margin(worst, reset != 0));
+  return TFHE_OK;
+#else
+  (void)worst;
+  (void)reset;
+  return fail(ctx, TFHE_ERR_UNSUPPORTED, "this build carries no rounding-margin probe (libtfhe_hip_probe.so does)");
+#endif
+}
+
 int tfhe_kernel_ms_ago(tfhe_context* ctx, unsigned steps_ago, float* blind_rotate_ms, float* key_switch_ms) {
   int st = check_ctx(ctx);
   if (st) return st;

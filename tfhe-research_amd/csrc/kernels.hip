@@ -1046,6 +1046,25 @@ hipError_t stream_copy(hipStream_t s, const void* src, void* dst, size_t bytes) 
   return hipGetLastError();
 }
 
+hipError_t fft_margin(double* worst, bool reset) {
+#if defined(TFHE_FFT_TRACK_ERROR)
+  unsigned long long bits = 0;
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpyFromSymbol(&bits, HIP_SYMBOL(g_fft_margin_bits), sizeof(bits));
+  if (e != hipSuccess) return e;
+  if (worst) __builtin_memcpy(worst, &bits, sizeof(bits));
+  if (reset) {
+    const unsigned long long zero = 0;
+    e = hipMemcpyToSymbol(HIP_SYMBOL(g_fft_margin_bits), &zero, sizeof(zero));
+  }
+  return e;
+#else
+  (void)worst;
+  (void)reset;
+  return hipErrorNotSupported;
+#endif
+}
+
 hipError_t lwe_linear(hipStream_t s, u32 c0, const u32* ct0, u32 c1, const u32* ct1, size_t words,
                       u32* out, size_t words_per_ct, u32 b_add) {
   hipLaunchKernelGGL(lwe_linear_kernel, dim3(grid_for(words, 256)), dim3(256), 0, s, c0, ct0, c1, ct1,

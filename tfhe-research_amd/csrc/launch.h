@@ -81,6 +81,10 @@ hipError_t lwe_body(hipStream_t s, const u32* rows, size_t row_count, u32 n, con
 hipError_t ggsw_add_gadget(hipStream_t s, u32* ggsw, size_t ggsw_count, u32 k, u32 log_n, u32 levels,
                            u32 log_base, u32 gadget_top, const u32* messages);
 
+// Probe builds (-DTFHE_FFT_TRACK_ERROR, libtfhe_hip_probe.so): largest |value - nearest integer| the complex
+// transform has lifted on the device since the last reset.  The product build has no probe: hipErrorNotSupported.
+hipError_t fft_margin(double* worst, bool reset);
+
 // dst[0..bytes) = src[0..bytes) with 16-byte accesses (bytes a multiple of 16): HBM roofline probe
 hipError_t stream_copy(hipStream_t s, const void* src, void* dst, size_t bytes);
 
