@@ -112,20 +112,28 @@ struct Monomial {
   int64_t index;
 };
 
-// The GPU context: owns the device-side (NTT-domain) copy of one BootstrappingKey.
+// The GPU engine: owns the device-side (NTT-domain) copies of ONE BootstrappingKey on one or several GPUs.
+// With a device list it is a pool (tfhe_pool_*, tfhe_hip.h): the key is uploaded and transformed once and the
+// prepared key replicated device to device; bootstrap_batch() and gate_batch() cut their batch into contiguous
+// slices, one per device; the single-ciphertext functions run on the first device.  Same bits either way.
 class Engine {
  public:
   // backend: TFHE_BACKEND_AUTO, or one of the transforms of tfhe_hip.h (every one returns the same bits;
   // TFHE_ERR_EXACTNESS / TFHE_ERR_UNSUPPORTED if the parameter set is outside the chosen one's bound or shapes)
-  explicit Engine(const TfheParams& params, int device = 0, int backend = TFHE_BACKEND_AUTO) : params_(params) {
+  explicit Engine(const TfheParams& params, int device = 0, int backend = TFHE_BACKEND_AUTO)
+      : Engine(params, std::vector<int>{device}, backend) {}
+  // one member per entry of `devices` (HIP device ordinals; an ordinal may repeat)
+  Engine(const TfheParams& params, const std::vector<int>& devices, int backend = TFHE_BACKEND_AUTO) : params_(params) {
     tfhe_params cp = params.c();
-    tfhe_context* raw = nullptr;
-    int st = tfhe_context_create_with_backend(&cp, device, backend, &raw);
-    if (st != TFHE_OK) throw TfheError(st, std::string("tfhe_context_create: ") + tfhe_status_string(st));
-    ctx_.reset(raw);
+    tfhe_pool* raw = nullptr;
+    int st = tfhe_pool_create(&cp, devices.data(), devices.size(), backend, &raw);
+    if (st != TFHE_OK) throw TfheError(st, std::string("tfhe_pool_create: ") + tfhe_status_string(st));
+    pool_.reset(raw);
+    ctx_ = tfhe_pool_member(raw, 0);
   }
   // "fp64-fft", "fp64-p49", "fp64-p42", "goldilocks" or "goldilocks-split"
-  std::string backend() const { return tfhe_context_backend(ctx_.get()); }
+  std::string backend() const { return tfhe_context_backend(ctx_); }
+  size_t devices() const { return tfhe_pool_size(pool_.get()); }
 
   // Uploads the key in the reference's own layout (n separate GGSW arrays + the KSK array).  A key of
   // the unrolled blind rotation (notes/BMMP Bootstrapping.md; bootstrapping_key_gen_bmmp below) holds
@@ -143,29 +151,34 @@ class Engine {
     const size_t ksk_words = params_.lwe_dimension_post_pbs() * params_.ks_decomposer.levels *
                              (size_t(params_.lwe_dimension) + 1);
     if (bk.ksk.data.size() != ksk_words) throw TfheError(TFHE_ERR_INVALID_ARGUMENT, "KSK shape");
-    check(bmmp ? tfhe_load_bootstrapping_key_bmmp(ctx_.get(), flat.data(), bk.ksk.data.data())
-               : tfhe_load_bootstrapping_key(ctx_.get(), flat.data(), bk.ksk.data.data()));
+    check_pool(bmmp ? tfhe_pool_load_bootstrapping_key_bmmp(pool_.get(), flat.data(), bk.ksk.data.data())
+                    : tfhe_pool_load_bootstrapping_key(pool_.get(), flat.data(), bk.ksk.data.data()));
   }
-  bool uses_bmmp() const { return tfhe_context_uses_bmmp(ctx_.get()) != 0; }
+  bool uses_bmmp() const { return tfhe_context_uses_bmmp(ctx_) != 0; }
 
   // Extensions beyond the reference (tfhe_hip.h): the aligned decomposer for bases with
   // beta^l != q, and the key-switch-then-PBS order of notes/TFHE.md:367-400 (ciphertexts of
   // k*N+1 words at the boundary).  Defaults are the reference's behaviour.
-  void set_decomposer_alignment(bool aligned) { check(tfhe_context_set_decomposer_alignment(ctx_.get(), aligned)); }
-  void set_bootstrap_order(bool ks_first) { check(tfhe_context_set_bootstrap_order(ctx_.get(), ks_first)); }
+  void set_decomposer_alignment(bool aligned) { check_pool(tfhe_pool_set_decomposer_alignment(pool_.get(), aligned)); }
+  void set_bootstrap_order(bool ks_first) { check_pool(tfhe_pool_set_bootstrap_order(pool_.get(), ks_first)); }
 
   const TfheParams& params() const { return params_; }
-  tfhe_context* raw() const { return ctx_.get(); }
+  tfhe_context* raw() const { return ctx_; }        // the first device's context (single-ciphertext calls)
+  tfhe_pool* raw_pool() const { return pool_.get(); }  // all devices (batch calls)
   void check(int st) const {
-    if (st != TFHE_OK) throw TfheError(st, std::string(tfhe_status_string(st)) + ": " + tfhe_last_error(ctx_.get()));
+    if (st != TFHE_OK) throw TfheError(st, std::string(tfhe_status_string(st)) + ": " + tfhe_last_error(ctx_));
+  }
+  void check_pool(int st) const {
+    if (st != TFHE_OK) throw TfheError(st, std::string(tfhe_status_string(st)) + ": " + tfhe_pool_last_error(pool_.get()));
   }
 
  private:
   struct Deleter {
-    void operator()(tfhe_context* c) const { tfhe_context_destroy(c); }
+    void operator()(tfhe_pool* p) const { tfhe_pool_destroy(p); }
   };
   TfheParams params_;
-  std::unique_ptr<tfhe_context, Deleter> ctx_;
+  std::unique_ptr<tfhe_pool, Deleter> pool_;
+  tfhe_context* ctx_ = nullptr;  // member 0, owned by the pool
 };
 
 // test_vector.rs:38-67
@@ -200,7 +213,8 @@ inline std::vector<LweCiphertext> bootstrap_batch(Engine& e, const std::vector<L
     if (cts[b].data.size() != n1) throw TfheError(TFHE_ERR_INVALID_ARGUMENT, "LWE length");
     std::copy(cts[b].data.begin(), cts[b].data.end(), in.begin() + b * n1);
   }
-  e.check(tfhe_bootstrap_batch(e.raw(), in.data(), cts.size(), test_vector_poly.data(), 1, out.data()));
+  // sharded over the engine's devices (one device: the plain single-context path)
+  e.check_pool(tfhe_pool_bootstrap_batch(e.raw_pool(), in.data(), cts.size(), test_vector_poly.data(), 1, out.data()));
   std::vector<LweCiphertext> res(cts.size());
   for (size_t b = 0; b < cts.size(); ++b) res[b].data.assign(out.begin() + b * n1, out.begin() + (b + 1) * n1);
   return res;
@@ -266,6 +280,22 @@ inline LweCiphertext gate(Engine& e, const uint32_t truth[4], const LweCiphertex
   LweCiphertext out{std::vector<uint32_t>(ct0.data.size())};
   e.check(tfhe_gate_batch(e.raw(), truth, ct0.data.data(), ct1.data.data(), 1, out.data.data()));
   return out;
+}
+// a stream of gates with one truth table, sharded over the engine's devices (boolean.rs:9-53 per pair)
+inline std::vector<LweCiphertext> gate_batch(Engine& e, const uint32_t truth[4], const std::vector<LweCiphertext>& ct0,
+                                             const std::vector<LweCiphertext>& ct1) {
+  if (ct0.size() != ct1.size() || ct0.empty()) throw TfheError(TFHE_ERR_INVALID_ARGUMENT, "gate_batch: equal, non-zero counts");
+  const size_t w = ct0[0].data.size();
+  std::vector<uint32_t> a(ct0.size() * w), b(ct0.size() * w), out(ct0.size() * w);
+  for (size_t i = 0; i < ct0.size(); ++i) {
+    if (ct0[i].data.size() != w || ct1[i].data.size() != w) throw TfheError(TFHE_ERR_INVALID_ARGUMENT, "LWE length");
+    std::copy(ct0[i].data.begin(), ct0[i].data.end(), a.begin() + i * w);
+    std::copy(ct1[i].data.begin(), ct1[i].data.end(), b.begin() + i * w);
+  }
+  e.check_pool(tfhe_pool_gate_batch(e.raw_pool(), truth, a.data(), b.data(), ct0.size(), out.data()));
+  std::vector<LweCiphertext> res(ct0.size());
+  for (size_t i = 0; i < ct0.size(); ++i) res[i].data.assign(out.begin() + i * w, out.begin() + (i + 1) * w);
+  return res;
 }
 inline LweCiphertext and_(Engine& e, const LweCiphertext& ct0, const LweCiphertext& ct1) {
   const uint32_t t[4] = {0, 0, 0, 1};

@@ -342,6 +342,52 @@ int tfhe_file_read_header(const char *path, uint32_t *kind, tfhe_params *params,
                           uint32_t dims[4], uint32_t *ndims, uint64_t *words);
 int tfhe_file_read(const char *path, uint32_t *data, uint64_t words);
 
+/* ---- multi-GPU pool ----------------------------------------------------------------
+ * The reference's shape is ONE BootstrappingKey (bootstrapping.rs:18-21) and many independent bootstrap() calls
+ * (bootstrapping.rs:58-65; the gates of boolean.rs:9-53 are one bootstrap each).  A pool holds one context per listed
+ * HIP device: the key is uploaded and transformed ONCE (member 0) and the PREPARED key is replicated device to device
+ * (peer copies over xGMI, concurrently on the destination members' streams -- not N host uploads and N prepares); a
+ * batch is cut into contiguous slices, slice i = [i*q + min(i, r), ...) of q = batch / n (+1 for the first r =
+ * batch % n members), and there is no collective anywhere in the data path.  Same bits as a single context: every
+ * bootstrap is a pure function of (ciphertext, test vector, keys).
+ * A device may be listed more than once (several members on one GPU); that is how a one-GPU box tests the pool.
+ * Host-pointer calls block until the results are in host memory and run one host thread per member; a pool must not
+ * be used from two threads at once. */
+typedef struct tfhe_pool tfhe_pool;
+int tfhe_pool_create(const tfhe_params *params, const int *devices, size_t n_devices, int backend,
+                     tfhe_pool **out);
+void tfhe_pool_destroy(tfhe_pool *pool);
+size_t tfhe_pool_size(const tfhe_pool *pool);
+/* Borrowed handle of member i (owned by the pool): for the per-context introspection calls (timing, backend name). */
+tfhe_context *tfhe_pool_member(tfhe_pool *pool, size_t i);
+const char *tfhe_pool_last_error(const tfhe_pool *pool);
+/* The slice of a batch member `member` processes: rows [*first, *first + *count). */
+int tfhe_pool_shard(const tfhe_pool *pool, size_t batch, size_t member, size_t *first, size_t *count);
+/* tfhe_context_set_decomposer_alignment / _set_bootstrap_order / _reserve / _synchronize for every member
+ * (reserve sizes each member for its slice of `max_batch`). */
+int tfhe_pool_set_decomposer_alignment(tfhe_pool *pool, int aligned);
+int tfhe_pool_set_bootstrap_order(tfhe_pool *pool, int ks_first);
+int tfhe_pool_reserve(tfhe_pool *pool, size_t max_batch);
+int tfhe_pool_synchronize(tfhe_pool *pool);
+/* BootstrappingKey upload, layouts as tfhe_load_bootstrapping_key: host pointers, or (_device) pointers on member
+ * 0's device. */
+int tfhe_pool_load_bootstrapping_key(tfhe_pool *pool, const uint32_t *bsk, const uint32_t *ksk);
+int tfhe_pool_load_bootstrapping_key_device(tfhe_pool *pool, const uint32_t *bsk, const uint32_t *ksk);
+/* the BMMP key of tfhe_load_bootstrapping_key_bmmp, replicated the same way */
+int tfhe_pool_load_bootstrapping_key_bmmp(tfhe_pool *pool, const uint32_t *bsk_bmmp, const uint32_t *ksk);
+/* bootstrap() over a host batch sharded across the members; arguments as tfhe_bootstrap_batch. */
+int tfhe_pool_bootstrap_batch(tfhe_pool *pool, const uint32_t *lwe_in, size_t batch,
+                              const uint32_t *test_vector_poly, size_t tv_count, uint32_t *lwe_out);
+/* and()/or()/... over a host batch sharded across the members; arguments as tfhe_gate_batch. */
+int tfhe_pool_gate_batch(tfhe_pool *pool, const uint32_t truth[4], const uint32_t *ct0,
+                         const uint32_t *ct1, size_t batch, uint32_t *lwe_out);
+/* Device-resident shards: member i bootstraps counts[i] ciphertexts at lwe_in[i] (a pointer on ITS device) with
+ * test vector(s) tv[i] (tv_counts[i] = 1 or counts[i]) into lwe_out[i].  Enqueues on every member's stream and
+ * returns; tfhe_pool_synchronize waits.  counts[i] = 0 skips a member. */
+int tfhe_pool_bootstrap_shards_device(tfhe_pool *pool, const uint32_t *const *lwe_in, const size_t *counts,
+                                      const uint32_t *const *test_vector_poly, const size_t *tv_counts,
+                                      uint32_t *const *lwe_out);
+
 /* ---- introspection for benchmarks --------------------------------------------------------- */
 /* Time of the blind-rotation kernel of the most recent bootstrap/blind_rotate call, measured with
  * HIP events on the context's stream (milliseconds); negative if none was recorded.  Enable with

@@ -26,13 +26,23 @@ pub struct CTfheParams {
 }
 
 #[repr(C)] pub struct TfheContext { _private: [u8; 0] }
+#[repr(C)] pub struct TfhePool { _private: [u8; 0] }
 
 extern "C" {
-    fn tfhe_context_create(params: *const CTfheParams, device: c_int, out: *mut *mut TfheContext) -> c_int;
-    fn tfhe_context_destroy(ctx: *mut TfheContext);
+    // multi-GPU pool (include/tfhe_hip.h, "multi-GPU pool"): one context per listed HIP device, ONE key prepared
+    // once and replicated device to device, batches cut into contiguous slices
+    fn tfhe_pool_create(params: *const CTfheParams, devices: *const c_int, n_devices: usize, backend: c_int,
+                        out: *mut *mut TfhePool) -> c_int;
+    fn tfhe_pool_destroy(pool: *mut TfhePool);
+    fn tfhe_pool_member(pool: *mut TfhePool, i: usize) -> *mut TfheContext;
+    fn tfhe_pool_last_error(pool: *const TfhePool) -> *const c_char;
+    fn tfhe_pool_load_bootstrapping_key(pool: *mut TfhePool, bsk: *const u32, ksk: *const u32) -> c_int;
+    fn tfhe_pool_load_bootstrapping_key_bmmp(pool: *mut TfhePool, bsk_bmmp: *const u32, ksk: *const u32) -> c_int;
+    fn tfhe_pool_bootstrap_batch(pool: *mut TfhePool, lwe_in: *const u32, batch: usize,
+                                 test_vector_poly: *const u32, tv_count: usize, lwe_out: *mut u32) -> c_int;
+    fn tfhe_pool_gate_batch(pool: *mut TfhePool, truth: *const u32, ct0: *const u32, ct1: *const u32,
+                            batch: usize, lwe_out: *mut u32) -> c_int;
     fn tfhe_last_error(ctx: *const TfheContext) -> *const c_char;
-    fn tfhe_load_bootstrapping_key(ctx: *mut TfheContext, bsk: *const u32, ksk: *const u32) -> c_int;
-    fn tfhe_load_bootstrapping_key_bmmp(ctx: *mut TfheContext, bsk_bmmp: *const u32, ksk: *const u32) -> c_int;
     fn tfhe_bootstrap_batch(ctx: *mut TfheContext, lwe_in: *const u32, batch: usize,
                             test_vector_poly: *const u32, tv_count: usize, lwe_out: *mut u32) -> c_int;
     fn tfhe_key_switch_batch(ctx: *mut TfheContext, lwe_in: *const u32, batch: usize, lwe_out: *mut u32) -> c_int;
@@ -62,45 +72,57 @@ fn check(ctx: *const TfheContext, status: c_int, what: &str) {
     }
 }
 
-/// Owns the GPU context and the device copy of one `BootstrappingKey` (bootstrapping.rs:18-21).
-pub struct GpuBootstrappingKey { ctx: *mut TfheContext, params: CTfheParams }
+fn check_pool(pool: *const TfhePool, status: c_int, what: &str) {
+    if status != 0 {
+        let msg = unsafe { std::ffi::CStr::from_ptr(tfhe_pool_last_error(pool)) }.to_string_lossy().into_owned();
+        panic!("{what}: status {status}: {msg}");
+    }
+}
+
+/// Owns the device copies of ONE `BootstrappingKey` (bootstrapping.rs:18-21) on one or several GPUs of a node.
+/// `pool` spans the listed devices; `ctx` is its first member (borrowed) and serves the single-ciphertext calls.
+pub struct GpuBootstrappingKey { pool: *mut TfhePool, ctx: *mut TfheContext, params: CTfheParams }
+
+/// All GPUs of an 8-GPU node: `&ALL_8_GPUS` as the `devices` argument below; `&[0]` is one GPU.
+pub const ALL_8_GPUS: [c_int; 8] = [0, 1, 2, 3, 4, 5, 6, 7];
 
 impl GpuBootstrappingKey {
-    /// `lwe_sk_ggsw_enc`: the n `GgswCiphertext.data` arrays ((k+1)l, k+1, N); `ksk`: `KeySwitchingKey.data`.
-    pub fn upload(params: CTfheParams, lwe_sk_ggsw_enc: &[Array3<u32>], ksk: &Array2<u32>) -> Self {
-        let mut ctx = std::ptr::null_mut();
-        let st = unsafe { tfhe_context_create(&params, 0, &mut ctx) };
-        assert!(st == 0, "tfhe_context_create: status {st}");
+    fn create(params: &CTfheParams, devices: &[c_int]) -> (*mut TfhePool, *mut TfheContext) {
+        let mut pool = std::ptr::null_mut();
+        let st = unsafe { tfhe_pool_create(params, devices.as_ptr(), devices.len(), 0 /* TFHE_BACKEND_AUTO */, &mut pool) };
+        assert!(st == 0, "tfhe_pool_create: status {st}");
+        (pool, unsafe { tfhe_pool_member(pool, 0) })
+    }
+
+    /// `lwe_sk_ggsw_enc`: the n `GgswCiphertext.data` arrays ((k+1)l, k+1, N); `ksk`: `KeySwitchingKey.data`;
+    /// `devices`: HIP device ordinals.  The key crosses PCIe once and is transformed once; the other devices get
+    /// the prepared key over xGMI.
+    pub fn upload(params: CTfheParams, devices: &[c_int], lwe_sk_ggsw_enc: &[Array3<u32>], ksk: &Array2<u32>) -> Self {
         let mut flat = Vec::new();
         for g in lwe_sk_ggsw_enc { flat.extend_from_slice(g.as_slice().unwrap()); }
-        check(ctx, unsafe { tfhe_load_bootstrapping_key(ctx, flat.as_ptr(), ksk.as_slice().unwrap().as_ptr()) }, "load key");
-        GpuBootstrappingKey { ctx, params }
+        Self::upload_flat(&params, devices, &flat, ksk.as_slice().unwrap())
     }
 
     /// The same from already flattened buffers: `bsk` [n][(k+1)l][k+1][N], `ksk` [kN*l_ks][n+1]
     /// (the layout of the on-disk format and of tests/golden/).
-    pub fn upload_flat(params: &CTfheParams, bsk: &[u32], ksk: &[u32]) -> Self {
-        let mut ctx = std::ptr::null_mut();
-        let st = unsafe { tfhe_context_create(params, 0, &mut ctx) };
-        assert!(st == 0, "tfhe_context_create: status {st}");
-        check(ctx, unsafe { tfhe_load_bootstrapping_key(ctx, bsk.as_ptr(), ksk.as_ptr()) }, "load key");
-        GpuBootstrappingKey { ctx, params: *params }
+    pub fn upload_flat(params: &CTfheParams, devices: &[c_int], bsk: &[u32], ksk: &[u32]) -> Self {
+        let (pool, ctx) = Self::create(params, devices);
+        check_pool(pool, unsafe { tfhe_pool_load_bootstrapping_key(pool, bsk.as_ptr(), ksk.as_ptr()) }, "load key");
+        GpuBootstrappingKey { pool, ctx, params: *params }
     }
 
     /// Key of the unrolled blind rotation the crate sketches in notes/BMMP Bootstrapping.md:13-25:
     /// `bsk_bmmp` [n/2][3][(k+1)l][k+1][N] = GGSW(s s'), GGSW(s (1-s')), GGSW(s' (1-s)) per pair of key
     /// bits.  `bootstrap` / the gates then consume two key bits per step (N = 512, even n).
-    pub fn upload_bmmp_flat(params: &CTfheParams, bsk_bmmp: &[u32], ksk: &[u32]) -> Self {
-        let mut ctx = std::ptr::null_mut();
-        let st = unsafe { tfhe_context_create(params, 0, &mut ctx) };
-        assert!(st == 0, "tfhe_context_create: status {st}");
-        check(ctx, unsafe { tfhe_load_bootstrapping_key_bmmp(ctx, bsk_bmmp.as_ptr(), ksk.as_ptr()) }, "load BMMP key");
-        GpuBootstrappingKey { ctx, params: *params }
+    pub fn upload_bmmp_flat(params: &CTfheParams, devices: &[c_int], bsk_bmmp: &[u32], ksk: &[u32]) -> Self {
+        let (pool, ctx) = Self::create(params, devices);
+        check_pool(pool, unsafe { tfhe_pool_load_bootstrapping_key_bmmp(pool, bsk_bmmp.as_ptr(), ksk.as_ptr()) }, "load BMMP key");
+        GpuBootstrappingKey { pool, ctx, params: *params }
     }
 }
 
 impl Drop for GpuBootstrappingKey {
-    fn drop(&mut self) { unsafe { tfhe_context_destroy(self.ctx) } }
+    fn drop(&mut self) { unsafe { tfhe_pool_destroy(self.pool) } }  // destroys the member contexts too
 }
 
 /// bootstrapping.rs:58-65.  `_lwe_secret_key` / `_glwe_secret_key` keep the positional slots of the
@@ -115,13 +137,25 @@ pub fn bootstrap<SK1, SK2>(bk: &GpuBootstrappingKey, lwe_ciphertext: &Array1<u32
     out
 }
 
-/// Batched form: `lwe_ciphertexts` is (batch, n+1) row-major.
+/// Batched form: `lwe_ciphertexts` is (batch, n+1) row-major.  Independent bootstraps: the batch is cut into
+/// contiguous slices over the devices the key was uploaded to (8 GPUs: batch 2^20 -> 2^17 per GPU); no collective.
 pub fn bootstrap_batch(bk: &GpuBootstrappingKey, lwe_ciphertexts: &Array2<u32>, test_vector_poly: &Array1<u32>) -> Array2<u32> {
     let mut out = Array2::<u32>::zeros(lwe_ciphertexts.raw_dim());
-    check(bk.ctx, unsafe {
-        tfhe_bootstrap_batch(bk.ctx, lwe_ciphertexts.as_slice().unwrap().as_ptr(), lwe_ciphertexts.nrows(),
-                             test_vector_poly.as_slice().unwrap().as_ptr(), 1, out.as_slice_mut().unwrap().as_mut_ptr())
+    check_pool(bk.pool, unsafe {
+        tfhe_pool_bootstrap_batch(bk.pool, lwe_ciphertexts.as_slice().unwrap().as_ptr(), lwe_ciphertexts.nrows(),
+                                  test_vector_poly.as_slice().unwrap().as_ptr(), 1, out.as_slice_mut().unwrap().as_mut_ptr())
     }, "bootstrap_batch");
+    out
+}
+
+/// A stream of gates with one truth table `truth[(lhs << 1) | rhs]` (boolean.rs:9-53 per row), sharded like
+/// bootstrap_batch: `ct0`, `ct1` are (batch, n+1).
+pub fn gate_batch(bk: &GpuBootstrappingKey, truth: [u32; 4], ct0: &Array2<u32>, ct1: &Array2<u32>) -> Array2<u32> {
+    let mut out = Array2::<u32>::zeros(ct0.raw_dim());
+    check_pool(bk.pool, unsafe {
+        tfhe_pool_gate_batch(bk.pool, truth.as_ptr(), ct0.as_slice().unwrap().as_ptr(), ct1.as_slice().unwrap().as_ptr(),
+                             ct0.nrows(), out.as_slice_mut().unwrap().as_mut_ptr())
+    }, "gate_batch");
     out
 }
 
@@ -180,16 +214,15 @@ pub fn construct_test_from_lut(params: &CTfheParams, lut: &[u32]) -> Array1<u32>
 pub fn bootstrapping_key_gen(params: CTfheParams, lwe_secret_key: &Array1<u32>, glwe_secret_key: &Array2<u32>,
                              mut bsk_samples: ndarray::Array4<u32>, mut ksk_samples: Array2<u32>)
                              -> (GpuBootstrappingKey, ndarray::Array4<u32>, Array2<u32>) {
-    let mut ctx = std::ptr::null_mut();
-    let st = unsafe { tfhe_context_create(&params, 0, &mut ctx) };
-    assert!(st == 0, "tfhe_context_create: status {st}");
+    // key generation runs on one GPU; upload_flat() the returned arrays to spread the key over more
+    let (pool, ctx) = GpuBootstrappingKey::create(&params, &[0]);
     check(ctx, unsafe {
         tfhe_bootstrapping_key_gen(ctx, lwe_secret_key.as_slice().unwrap().as_ptr(),
                                    glwe_secret_key.as_slice().unwrap().as_ptr(),
                                    bsk_samples.as_slice_mut().unwrap().as_mut_ptr(),
                                    ksk_samples.as_slice_mut().unwrap().as_mut_ptr(), 1)
     }, "bootstrapping_key_gen");
-    (GpuBootstrappingKey { ctx, params }, bsk_samples, ksk_samples)
+    (GpuBootstrappingKey { pool, ctx, params }, bsk_samples, ksk_samples)
 }
 
 /// encrypt_lwe_plaintext (lwe.rs:138-160) over a batch: `samples` (batch, n+1) holds the uniform

@@ -38,7 +38,7 @@ fn replay(set: &str) {
     };
     let bsk = Array4::from_shape_vec((bd[0], bd[1], bd[2], bd[3]), bsk).unwrap();
     let ksk = Array2::from_shape_vec((kd[0], kd[1]), ksk).unwrap();
-    let key = GpuBootstrappingKey::upload_flat(&params, bsk.as_slice().unwrap(), ksk.as_slice().unwrap());
+    let key = GpuBootstrappingKey::upload_flat(&params, &[0], bsk.as_slice().unwrap(), ksk.as_slice().unwrap());
     let batch = Array2::from_shape_vec((ld[0], ld[1]), lwe_in).unwrap();
     let got = tfhe_hip_sys::bootstrap_batch(&key, &batch, &Array1::from_vec(tv));
     assert_eq!(got.as_slice().unwrap(), &lwe_out[..], "{set}");

@@ -223,6 +223,37 @@ int main() {
     } catch (const TfheError&) { threw = true; }
     EXPECT(threw, "invalid decomposer rejected");
   }
+  // One BootstrappingKey, many independent bootstrap() calls, several devices: an Engine over a device list
+  // (here the one GPU listed twice) shards the batch and must give the single-device engine's bits; so must a
+  // stream of NAND gates (boolean.rs:9-53)
+  {
+    Engine pool(tfhe_params, std::vector<int>{0, 0});
+    pool.load(bootstrapping_key);
+    EXPECT(pool.devices() == 2, "two members");
+    auto test_vector_poly = construct_identity_test_vector(tfhe_params);
+    std::vector<LweCiphertext> cts, cts2;
+    for (uint32_t i = 0; i < 7; ++i) {
+      cts.push_back(encrypt(i & 3u));
+      cts2.push_back(encrypt((i >> 1) & 1u));
+    }
+    auto one = bootstrap_batch(engine, cts, test_vector_poly);
+    auto two = bootstrap_batch(pool, cts, test_vector_poly);
+    bool same = one.size() == two.size();
+    for (size_t i = 0; same && i < one.size(); ++i) same = one[i].data == two[i].data;
+    EXPECT(same, "pooled bootstrap_batch == single-device bootstrap_batch");
+    for (uint32_t i = 0; i < 7; ++i) EXPECT(decrypt(two[i]) == (i & 3u), "pooled bootstrap decrypts");
+    const uint32_t nand_t[4] = {1, 1, 1, 0};
+    std::vector<LweCiphertext> bits0, bits1;
+    for (uint32_t i = 0; i < 5; ++i) {
+      bits0.push_back(encrypt(i & 1u));
+      bits1.push_back(encrypt((i >> 1) & 1u));
+    }
+    auto gates = gate_batch(pool, nand_t, bits0, bits1);
+    for (uint32_t i = 0; i < 5; ++i) {
+      EXPECT(gates[i].data == nand(engine, bits0[i], bits1[i]).data, "pooled NAND == single-device NAND");
+      EXPECT(decrypt(gates[i]) == (1u - ((i & 1u) & ((i >> 1) & 1u))), "pooled NAND decrypts");
+    }
+  }
   if (failures) {
     std::fprintf(stderr, "%d failure(s)\n", failures);
     return 1;

@@ -115,7 +115,7 @@ def test_external_product_at_the_bound_with_random_signs(oracle, name, k, logn, 
         got = ctx.external_product(ggsw, glwe)
         shared = ctx.external_product(ggsw[0], glwe)
         aut = None
-        if ctx.backend() != "goldilocks-split":
+        if ctx.backend != "goldilocks-split":
             # an independent exact route for the rows the oracle does not redo: Goldilocks-split lifts every base
             m = pkg()
             with m.Context(to_pkg_params(p), backend=m.BACKEND_GOLDILOCKS_SPLIT) as ref:
@@ -136,13 +136,13 @@ def test_auto_picks_fft_at_the_admission_edge(oracle):
             continue
         p = oracle.Params(k, logn, 4, oracle.Decomposer(*pbs))
         with m.Context(to_pkg_params(p)) as ctx:
-            assert ctx.backend() == "fp64-fft", (name, ctx.backend())
+            assert ctx.backend == "fp64-fft", (name, ctx.backend)
     p = oracle.Params(2, 10, 4, oracle.Decomposer(12, 2))
     with pytest.raises(m.TfheError) as e:
         m.Context(to_pkg_params(p), backend=m.BACKEND_FP64_FFT)
     assert e.value.status == m.TFHE_ERR_EXACTNESS
     with m.Context(to_pkg_params(p)) as ctx:     # AUTO falls through to an exact field that lifts it
-        assert ctx.backend() in ("goldilocks", "goldilocks-split")
+        assert ctx.backend in ("goldilocks", "goldilocks-split")
 
 
 @pytest.mark.parametrize("backend", BACKENDS)

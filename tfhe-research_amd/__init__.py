@@ -863,3 +863,141 @@ class Context:
         shift = 32 - p.log_p - p.padding_bits
         raw = self.lwe_decrypt(lwe_sk, lwe).astype(np.uint64)
         return (((raw + (1 << (shift - 1))) >> shift) & ((1 << p.log_p) - 1)).astype(np.uint32)
+
+
+class _BorrowedContext(Context):
+    """A pool member's context handle: owned by the pool, never destroyed from here."""
+
+    def __init__(self, params: TfheParams, handle):
+        self.params = params
+        self._h = C.c_void_p(handle)
+        lib().tfhe_context_backend.restype = C.c_char_p
+
+    def close(self):
+        self._h = C.c_void_p()
+
+
+class Pool:
+    """Multi-GPU behind the C ABI (tfhe_pool_*): one context per listed device, ONE BootstrappingKey
+    (bootstrapping.rs:18-21) prepared once and replicated device to device, batches of independent bootstrap() calls
+    (bootstrapping.rs:58-65) cut into contiguous slices, no collective in the data path.  A device may be listed
+    more than once (several members on one GPU)."""
+
+    def __init__(self, params: TfheParams, devices, backend: int = BACKEND_AUTO):
+        self.params = params
+        self.devices = [int(d) for d in devices]
+        self._h = C.c_void_p()
+        cp = params._c()
+        arr = (C.c_int * len(self.devices))(*self.devices)
+        lib().tfhe_pool_last_error.restype = C.c_char_p
+        lib().tfhe_pool_member.restype = C.c_void_p
+        lib().tfhe_pool_size.restype = C.c_size_t
+        st = lib().tfhe_pool_create(C.byref(cp), arr, C.c_size_t(len(self.devices)), C.c_int(backend), C.byref(self._h))
+        if st:
+            self._h = C.c_void_p()
+            raise TfheError(st, lib().tfhe_status_string(st).decode())
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().tfhe_pool_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, st: int):
+        if st:
+            raise TfheError(st, lib().tfhe_pool_last_error(self._h).decode())
+
+    def __len__(self) -> int:
+        return lib().tfhe_pool_size(self._h)
+
+    def member(self, i: int) -> Context:
+        """borrowed context of member i (timing, backend name); owned by the pool"""
+        h = lib().tfhe_pool_member(self._h, C.c_size_t(i))
+        if not h:
+            raise IndexError(i)
+        return _BorrowedContext(self.params, h)
+
+    @property
+    def backend(self) -> str:
+        return self.member(0).backend
+
+    def shard(self, batch: int, member: int):
+        """(first row, row count) of the slice member `member` processes"""
+        first, count = C.c_size_t(), C.c_size_t()
+        self._check(lib().tfhe_pool_shard(self._h, C.c_size_t(batch), C.c_size_t(member), C.byref(first), C.byref(count)))
+        return first.value, count.value
+
+    def set_decomposer_alignment(self, aligned: bool):
+        self._check(lib().tfhe_pool_set_decomposer_alignment(self._h, C.c_int(int(aligned))))
+
+    def set_bootstrap_order(self, ks_first: bool):
+        self._check(lib().tfhe_pool_set_bootstrap_order(self._h, C.c_int(int(ks_first))))
+        self._ks_first = bool(ks_first)
+
+    @property
+    def io_dim(self) -> int:
+        return self.params.big_n if getattr(self, "_ks_first", False) else self.params.n
+
+    def reserve(self, max_batch: int):
+        self._check(lib().tfhe_pool_reserve(self._h, C.c_size_t(max_batch)))
+
+    def synchronize(self):
+        self._check(lib().tfhe_pool_synchronize(self._h))
+
+    def load_bootstrapping_key(self, bsk, ksk):
+        """bsk [n][R][k+1][N], ksk [k*N*l_ks][n+1]: numpy (host) or torch tensors on member 0's device.  Uploaded and
+        transformed once; the prepared key is copied device to device to the other members."""
+        p = self.params
+        if _is_torch(bsk):
+            assert tuple(bsk.shape) == p.bsk_shape() and tuple(ksk.shape) == p.ksk_shape()
+            import torch
+            torch.cuda.synchronize(bsk.device)
+            self._check(lib().tfhe_pool_load_bootstrapping_key_device(self._h, _dp(bsk), _dp(ksk)))
+            return
+        bsk, ksk = _np(bsk), _np(ksk)
+        assert bsk.shape == p.bsk_shape() and ksk.shape == p.ksk_shape()
+        self._check(lib().tfhe_pool_load_bootstrapping_key(self._h, _hp(bsk), _hp(ksk)))
+
+    def bootstrap(self, lwe_in, test_vector_poly) -> np.ndarray:
+        """bootstrap() over a host batch [batch][n+1], sharded over the members"""
+        lwe, tv = _np(lwe_in).reshape(-1, self.io_dim + 1), _np(test_vector_poly)
+        tv_count = 1 if tv.ndim == 1 else tv.shape[0]
+        res = np.zeros_like(lwe)
+        self._check(lib().tfhe_pool_bootstrap_batch(self._h, _hp(lwe), C.c_size_t(lwe.shape[0]), _hp(tv),
+                                                    C.c_size_t(tv_count), _hp(res)))
+        return res
+
+    def gate(self, truth, ct0, ct1) -> np.ndarray:
+        """boolean.rs:9-53 over a host batch, sharded over the members"""
+        c0, c1 = _np(ct0).reshape(-1, self.io_dim + 1), _np(ct1).reshape(-1, self.io_dim + 1)
+        t = (C.c_uint32 * 4)(*[int(v) for v in truth])
+        res = np.zeros_like(c0)
+        self._check(lib().tfhe_pool_gate_batch(self._h, t, _hp(c0), _hp(c1), C.c_size_t(c0.shape[0]), _hp(res)))
+        return res
+
+    def bootstrap_shards(self, lwe_shards, tv_shards, out_shards):
+        """Device-resident shards (torch tensors, shard i on member i's device; None or an empty shard skips the
+        member): enqueues on every member's stream and returns -- synchronize() waits."""
+        n = len(self)
+        assert len(lwe_shards) == n and len(tv_shards) == n and len(out_shards) == n
+        ptrs_in, ptrs_tv, ptrs_out = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_void_p * n)()
+        counts, tv_counts = (C.c_size_t * n)(), (C.c_size_t * n)()
+        for i in range(n):
+            rows = 0 if lwe_shards[i] is None else int(lwe_shards[i].shape[0])
+            counts[i] = rows
+            if rows == 0:
+                continue
+            ptrs_in[i], ptrs_tv[i], ptrs_out[i] = lwe_shards[i].data_ptr(), tv_shards[i].data_ptr(), out_shards[i].data_ptr()
+            tv_counts[i] = 1 if tv_shards[i].dim() == 1 else int(tv_shards[i].shape[0])
+        self._check(lib().tfhe_pool_bootstrap_shards_device(self._h, ptrs_in, counts, ptrs_tv, tv_counts, ptrs_out))

@@ -3,9 +3,7 @@
 // Host-side only logic: parameter validation (mirrors what makes the reference panic), device
 // memory management, key preparation and kernel sequencing.  No CPU implementation of the hot
 // path lives here: without a GPU every compute entry point fails with TFHE_ERR_NO_DEVICE.
-#include "tfhe_hip.h"
-
-#include <hip/hip_runtime.h>
+#include "context.h"
 
 #include <cmath>
 #include <cstdint>
@@ -17,91 +15,10 @@
 #include <string>
 #include <vector>
 
-#include "launch.h"
-
-using namespace tfhe;
-
-struct tfhe_context {
-  tfhe_params params;
-  PbsParams pbs;
-  KsParams ks;
-  int device = 0;
-  hipStream_t stream = nullptr;
-  bool own_stream = false;
-  u32 N = 0, R = 0, big_n = 0;
-
-  int field = 0;              // launch::kFieldGoldilocks | launch::kFieldFp64
-  int parts = 1;              // spectra per key polynomial in this field
-  void* d_tw = nullptr;       // psi_rev[N], 8-byte field elements
-  unsigned long long* d_queue = nullptr;  // ticket counter of the external-product kernel's work queue
-  void* d_bsk = nullptr;      // prepared BSK [n][R][k+1][parts][N] (spectrum_slot order, x 1/N)
-  u32* d_ksk = nullptr;       // [big_n*l_ks][n+1]
-  bool have_key = false;
-  bool bmmp = false;          // the loaded key is a BMMP key: n/2 * 3 GGSWs (tfhe_load_bootstrapping_key_bmmp)
-  size_t bsk_ggsws = 0;       // GGSWs d_bsk was allocated for
-  bool aligned = false;       // decomposer alignment (tfhe_context_set_decomposer_alignment)
-  bool ks_first = false;      // bootstrap order (tfhe_context_set_bootstrap_order)
-
-  // workspace (grown on demand by host-pointer calls or tfhe_context_reserve)
-  size_t ws_batch = 0;
-  u32* d_lwe_in = nullptr;    // [batch][n+1]
-  u32* d_lwe_in2 = nullptr;   // [batch][n+1] second gate operand
-  u32* d_lwe_big = nullptr;   // [batch][big_n+1]
-  u32* d_lwe_out = nullptr;   // [batch][n+1]
-  u32* d_lwe_ks = nullptr;    // [batch][n+1] key-switched input of the KS-then-PBS order
-  u32* d_glwe_a = nullptr;    // [batch][k+1][N]
-  u32* d_glwe_b = nullptr;
-  u32* d_glwe_c = nullptr;
-  u32* d_tv = nullptr;        // [batch][N] (or [1][N])
-  // test vectors of gate calls, one [N] device buffer per truth table seen (a gate graph alternates
-  // between a handful of tables; re-uploading on every switch would synchronise the stream)
-  struct GateTv {
-    std::vector<u32> truth;  // 2^inputs entries
-    u32* d_tv = nullptr;
-    unsigned long long last_use = 0;
-  };
-  std::vector<GateTv> gate_tvs;
-  unsigned long long gate_clock = 0;
-  // generic scratch for the small entry points
-  void* d_misc = nullptr;
-  size_t misc_bytes = 0;
-  u64* d_ggsw_tmp = nullptr;  // prepared GGSWs of external_product / cmux host calls (8-byte words)
-  size_t ggsw_tmp_words = 0;
-  u32* d_ggsw_raw = nullptr;
-  size_t ggsw_raw_words = 0;
-  u32* d_key_tmp = nullptr;   // secret keys / messages of the encryption-side calls
-  size_t key_tmp_words = 0;
-
-  bool timing = false;
-  // br start/stop, ks start/stop of the current timing slot.  Bootstraps rotate through kTimingSlots sets of
-  // events, so that a caller can time K back-to-back steps without a host synchronisation inside the loop and
-  // read them all afterwards (tfhe_kernel_ms_ago); the other timed calls use the current set.
-  static constexpr int kTimingSlots = 64;
-  hipEvent_t ev_ring[kTimingSlots][4] = {};
-  hipEvent_t* ev = ev_ring[0];
-  int ev_slot = 0;
-  unsigned long long timed_bootstraps = 0;
-  bool ev_valid_br = false, ev_valid_ks = false;
-
-  std::string last_error;
-};
-
 namespace {
 
-int fail(tfhe_context* ctx, int status, const std::string& msg) {
-  if (ctx) ctx->last_error = msg;
-  return status;
-}
-
-int hip_fail(tfhe_context* ctx, hipError_t e, const char* what) {
-  return fail(ctx, TFHE_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
-}
-
-#define HIP_TRY(ctx, expr)                                        \
-  do {                                                            \
-    hipError_t _e = (expr);                                       \
-    if (_e != hipSuccess) return hip_fail((ctx), _e, #expr);      \
-  } while (0)
+using tfhe::host::fail;
+using tfhe::host::hip_fail;
 
 // Bit just above the most significant limb: gadget factor of level i is 2^{top - log_base*(i+1)} and
 // the lowest kept limb starts at top - log_base*levels.  Literal (reference, decomposer.rs:48-70 /
@@ -211,9 +128,7 @@ int check_tv_host(tfhe_context* ctx, const u32* tv, size_t words) {
 // Enqueue the whole PBS on device buffers: blind rotation (+ fused sample extract), key switch.
 // words of one ciphertext at the bootstrap boundary: n+1 in the reference's order (PBS then KS,
 // bootstrapping.rs:58-120), k*N+1 when the key switch comes first
-size_t io_words(const tfhe_context* ctx) {
-  return (ctx->ks_first ? (size_t)ctx->big_n : (size_t)ctx->params.lwe_dimension) + 1;
-}
+using tfhe::host::io_words;
 
 // the blind rotation the loaded key calls for: bootstrapping.rs:79-105, or the unrolled loop of
 // notes/BMMP Bootstrapping.md with a BMMP key
@@ -287,6 +202,56 @@ hipError_t upload_twiddles(tfhe_context* ctx) {
 }
 
 }  // namespace
+
+namespace tfhe {
+namespace host {
+
+size_t io_words(const tfhe_context* ctx) {
+  return (ctx->ks_first ? (size_t)ctx->big_n : (size_t)ctx->params.lwe_dimension) + 1;
+}
+
+int adopt_prepared_key(tfhe_context* dst, const tfhe_context* src) {
+  if (!dst || !src || !src->have_key) return fail(dst, TFHE_ERR_NO_KEY, "source context holds no key");
+  if (std::memcmp(&dst->params, &src->params, sizeof(tfhe_params)) != 0 || dst->field != src->field ||
+      dst->aligned != src->aligned)
+    return fail(dst, TFHE_ERR_INVALID_PARAMS, "pool members must share parameters, backend and decomposer alignment");
+  HIP_TRY(dst, hipSetDevice(dst->device));
+  const size_t ggsws = src->bsk_ggsws;
+  const size_t bsk_bytes = ggsws * src->R * (src->params.glwe_dimension + 1) * (size_t)src->parts * src->N * sizeof(u64);
+  const size_t ksk_bytes = (size_t)src->big_n * src->ks.levels * ((size_t)src->params.lwe_dimension + 1) * sizeof(u32);
+  if (dst->d_bsk && dst->bsk_ggsws != ggsws) {
+    HIP_TRY(dst, hipStreamSynchronize(dst->stream));
+    dst->have_key = false;
+    hipError_t e = hipFree(dst->d_bsk);
+    dst->d_bsk = nullptr;
+    if (e != hipSuccess) return hip_fail(dst, e, "hipFree(bsk)");
+  }
+  if (!dst->d_bsk) {
+    HIP_TRY(dst, hipMalloc(&dst->d_bsk, bsk_bytes));
+    dst->bsk_ggsws = ggsws;
+  }
+  if (!dst->d_ksk) HIP_TRY(dst, hipMalloc(reinterpret_cast<void**>(&dst->d_ksk), ksk_bytes));
+  if (dst->device == src->device) {
+    HIP_TRY(dst, hipMemcpyAsync(dst->d_bsk, src->d_bsk, bsk_bytes, hipMemcpyDeviceToDevice, dst->stream));
+    HIP_TRY(dst, hipMemcpyAsync(dst->d_ksk, src->d_ksk, ksk_bytes, hipMemcpyDeviceToDevice, dst->stream));
+  } else {
+    // direct xGMI copies where the link allows peer access; hipMemcpyPeerAsync stages through the host otherwise
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, dst->device, src->device) == hipSuccess && can) {
+      hipError_t e = hipDeviceEnablePeerAccess(src->device, 0);
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return hip_fail(dst, e, "hipDeviceEnablePeerAccess");
+      (void)hipGetLastError();
+    }
+    HIP_TRY(dst, hipMemcpyPeerAsync(dst->d_bsk, dst->device, src->d_bsk, src->device, bsk_bytes, dst->stream));
+    HIP_TRY(dst, hipMemcpyPeerAsync(dst->d_ksk, dst->device, src->d_ksk, src->device, ksk_bytes, dst->stream));
+  }
+  dst->have_key = true;
+  dst->bmmp = src->bmmp;
+  return TFHE_OK;
+}
+
+}  // namespace host
+}  // namespace tfhe
 
 extern "C" {
 
