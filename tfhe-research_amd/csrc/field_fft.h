@@ -8,10 +8,10 @@
 //     T[h + i] = exp(i pi (1 + 4 bitrev_s(i)) / (4h)),   h = 2^s, i < h,
 // and no separate twist.  The inverse butterfly multiplies by -conj(T[h + i]) (|T| = 1).
 //
-// Why: a complex butterfly is 8 fp64 instructions like the 42-bit field's, but there are half as many
-// (M/2 log2 M instead of N/2 log2 N per transform) and a multiply-accumulate term is 4 FMAs for TWO
-// coefficients instead of 7 instructions for one -- 2,600 instead of 5,090 VALU instructions per wave
-// and CMUX iteration at N = 1024, k = 1, l = 3.
+// Why: a complex butterfly is 8 fp64 instructions like the 42-bit field's (6 in the forward direction, see
+// butterfly_forward), but there are half as many (M/2 log2 M instead of N/2 log2 N per transform) and a
+// multiply-accumulate term is 4 FMAs for TWO coefficients instead of 7 instructions for one -- 2,300 instead of
+// 5,090 VALU instructions per wave and CMUX iteration at N = 1024, k = 1, l = 3.
 //
 // Exactness.  The values are NOT exact integers on the way; the final result is: the inverse transform
 // returns z~_j = z_j + e_j with z_j the integer convolution value, and |e_j| < 1/2 makes
@@ -19,8 +19,9 @@
 // a radix-2 FFT of n stages computed with twiddles of absolute error <= mu satisfies
 // ||X~ - X||_2 <= n eta / (1 - n eta) ||X||_2, eta = mu + gamma_4 (sqrt 2 + mu), gamma_4 = 4u / (1 - 4u),
 // u = 2^-53; our twiddles are correctly rounded from long double, each component within u/2, |error| <= u / sqrt 2,
-// so eta <= 7.1 u = 7.9e-16 with room to spare; FMA
-// butterflies only tighten it).  With x the folded digits (|x_j| <= sqrt 2 B), y the folded key half
+// so eta <= 7.1 u = 7.9e-16 with room to spare; the forward transforms here use a six-FMA butterfly whose own
+// per-stage perturbation is 4.32 u, derived at FftField::butterfly_forward below; the inverse ones the textbook
+// sum / difference-times-twiddle form).  With x the folded digits (|x_j| <= sqrt 2 B), y the folded key half
 // (|y_j| <= sqrt 2 2^15), X, Y their unnormalised transforms (||X||_2 <= M |x|max, ||Y||_inf <= M |y|max),
 // R = (k+1) l rows accumulated in the transform domain, n = log2 M stages:
 //   forward errors   ||X~ - X||_2 <= n eta M |x|,  the same for Y (the prepared key)
@@ -116,6 +117,27 @@ struct FftField {
   // complex product, 2 multiplications + 2 FMAs
   TFHE_HD static elem mul(elem a, elem w) {
     return elem{__builtin_fma(a.re, w.re, -(a.im * w.im)), __builtin_fma(a.re, w.im, a.im * w.re)};
+  }
+  // The forward butterfly (u + w b, u - w b) in SIX fused multiply-adds instead of a complex product (4) and two
+  // complex sums (4): y0 = u + w b is two chained FMAs per component, and y1 = u - w b = 2 u - y0 one more.
+  // Its rounding stays inside the eta the bound above is evaluated with.  With a = u, U = 2^-53, A = |a|, B = |b|:
+  //   y0.re = fl(fl(a.re + w.re b.re) - w.im b.im): |error| <= U (2 |a.re| + 2 |w.re b.re| + |w.im b.im|), the same
+  //   shape for y0.im, so |y0~ - (a + w^ b)| <= U (2 A + sqrt 5 B); the stored twiddle w^ adds |w^ - w| B <= U B / sqrt 2:
+  //   |y0~ - y0| <= U (2 A + 2.95 B);
+  //   y1~ = fl(2 a - y0~) = (y1 - (y0~ - y0)) (1 + d): |y1~ - y1| <= |y0~ - y0| + U (A + B) <= U (3 A + 3.95 B).
+  // The pair's error vector has 2-norm <= U sqrt((2A + 2.95B)^2 + (3A + 3.95B)^2) <= 6.11 U sqrt(A^2 + B^2) (largest
+  // eigenvalue of [[13, 17.75], [17.75, 24.305]] is 37.28), and a stage multiplies the 2-norm of its input by exactly
+  // sqrt 2: the stage's relative perturbation is <= 6.11 / sqrt 2 = 4.32 U < eta = 7.1 U -- Higham's Theorem 24.2 only
+  // needs ||dA_k||_2 <= eta ||A_k||_2 per stage, whatever the order of the operations inside the butterfly.
+#ifndef TFHE_FFT_FMA_BUTTERFLY
+#define TFHE_FFT_FMA_BUTTERFLY 1  // 0: the 8-instruction product + two sums (A/B builds only)
+#endif
+  static constexpr bool kFusedForwardButterfly = TFHE_FFT_FMA_BUTTERFLY != 0;
+  TFHE_HD static void butterfly_forward(elem u, elem b, elem w, elem& y0, elem& y1) {
+    const double re = __builtin_fma(-b.im, w.im, __builtin_fma(b.re, w.re, u.re));
+    const double im = __builtin_fma(b.im, w.re, __builtin_fma(b.re, w.im, u.im));
+    y0 = elem{re, im};
+    y1 = elem{__builtin_fma(2.0, u.re, -re), __builtin_fma(2.0, u.im, -im)};
   }
   // a * (-conj(w)): the inverse butterfly's twiddle
   TFHE_HD static elem mul_inverse(elem a, elem w) {

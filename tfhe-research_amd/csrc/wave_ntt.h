@@ -286,6 +286,16 @@ struct TopConsts {
   }
 };
 
+// fields whose forward butterfly is one fused step (F::kFusedForwardButterfly + F::butterfly_forward)
+template <class F, class = void>
+struct FusedForwardButterfly {
+  static constexpr bool value = false;
+};
+template <class F>
+struct FusedForwardButterfly<F, decltype((void)F::kFusedForwardButterfly)> {
+  static constexpr bool value = F::kFusedForwardButterfly;
+};
+
 // XOR swizzle of the transpose buffer (element = 8 bytes).  Each one makes every ds_write_b64 and
 // ds_read_b64 of both transposes, in both directions, bank-conflict free (tools/ntt_model.py).
 template <int LOGN, int G>
@@ -432,9 +442,14 @@ TFHE_HD void ntt_pass_forward(const Ctx& c, typename F::elem (&x)[NttShape<LOGN,
                      : ntt_twiddles_transposed<(int)sizeof(elem)>() ? tw[m + (r0 >> (rb + 1)) * H + hi]
                                           : tw[m + (hi << (LO + e - b - 1)) + (r0 >> (rb + 1))];
       const elem u = x[r0];
-      const elem v = (SMALL_FIRST && b == BHI) ? F::mul_small(x[r1], w) : F::mul(x[r1], w);
-      x[r0] = F::add(u, v);
-      x[r1] = F::sub(u, v);
+      if constexpr (FusedForwardButterfly<F>::value) {
+        // (u + w x1, u - w x1) in six fused multiply-adds instead of a product and two sums (field_fft.h)
+        F::butterfly_forward(u, x[r1], w, x[r0], x[r1]);
+      } else {
+        const elem v = (SMALL_FIRST && b == BHI) ? F::mul_small(x[r1], w) : F::mul(x[r1], w);
+        x[r0] = F::add(u, v);
+        x[r1] = F::sub(u, v);
+      }
     }
   }
 }

@@ -7,4 +7,4 @@ OUT="$1"; LOGN="$2"; K="$3"; shift 3
 /opt/rocm/bin/hipcc -O3 -std=c++17 -ffp-contract=off --offload-arch=gfx950 -fPIC -shared \
   -DTFHE_WAVES_PER_SIMD_FP=2 -DTFHE_WAVES_PER_SIMD_GL=2 -DTFHE_DEV_CFG2_ONLY -DTFHE_DEV_LOGN=$LOGN -DTFHE_DEV_K=$K "$@" \
   -I "$ROOT/include" -I "$ROOT/tfhe-research_amd/csrc" \
-  "$ROOT/tfhe-research_amd/csrc/kernels.hip" "$ROOT/tfhe-research_amd/csrc/capi.cpp" -o "$OUT"
+  "$ROOT/tfhe-research_amd/csrc/kernels.hip" "$ROOT/tfhe-research_amd/csrc/capi.cpp" "$ROOT/tfhe-research_amd/csrc/pool.cpp" -o "$OUT"
