@@ -271,6 +271,15 @@ int emu_field_shape_ok(int field, int logn, int g) {
   if (field != 5) return 1;
   return ((logn == 9 || logn == 10) && g == 1) || logn == 11;
 }
+// the hoisted-constant rounding of the hot loop against the literal decomposer.rs:27-40 restatement: number of
+// mismatches over `count` words starting at `first` with stride `stride`
+unsigned long long emu_round_value_mismatches(unsigned ignored_bits, unsigned first, unsigned stride, unsigned long long count) {
+  const RoundConsts rc = round_consts(ignored_bits);
+  unsigned long long bad = 0;
+  u32 v = first;
+  for (unsigned long long i = 0; i < count; ++i, v += stride) bad += round_value_fast(v, rc) != round_value(v, ignored_bits);
+  return bad;
+}
 double emu_fft_error_bound(int logn, int rows, int log_base) { return FftField::error_bound(logn, rows, log_base); }
 // largest |value - nearest integer| the complex transform has lifted since the last reset
 void emu_fft_error_reset() { fft_error_slot().store(0.0); }

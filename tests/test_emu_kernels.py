@@ -354,6 +354,18 @@ def test_fft_rounding_margin(emu, oracle, k, logn, pbs, g):
     print(f"fft rounding margin N=2^{logn} k={k} rows={rows} B=2^{log_base}: measured {worst:.3g}, proven bound {bound:.3g}")
 
 
+def test_hoisted_rounding_equals_the_literal_one(emu):
+    """round_value_fast ((v + half) & keep, the hot loop's two-instruction form) against round_value (decomposer.rs:27-40
+    restated literally) for every number of ignored bits: the words around every wrap and carry, and a strided sweep of
+    the whole u32 range"""
+    emu.emu_round_value_mismatches.restype = C.c_ulonglong
+    for ig in range(0, 32):
+        assert emu.emu_round_value_mismatches(ig, 0, 1, C.c_ulonglong(1 << 16)) == 0
+        assert emu.emu_round_value_mismatches(ig, 0xFFFF0000, 1, C.c_ulonglong(1 << 16)) == 0
+        assert emu.emu_round_value_mismatches(ig, 0x7FFF8000, 1, C.c_ulonglong(1 << 16)) == 0
+        assert emu.emu_round_value_mismatches(ig, 12345, 65521, C.c_ulonglong(1 << 18)) == 0
+
+
 def test_fft_error_bound_is_quadratic_in_the_rows():
     """The accumulation term of the bound: R products summed by an FMA chain round the running sum R times, so the
     rounding part grows like R (R + 1), not like R.  Pinned numbers of the corrected formula."""

@@ -139,6 +139,15 @@ struct FftField {
     y0 = elem{re, im};
     y1 = elem{__builtin_fma(2.0, u.re, -re), __builtin_fma(2.0, u.im, -im)};
   }
+  // The inverse butterfly (u + v, (v - u) (-conj w)) written as (u - v) conj(w): the same value, and no result has to
+  // be negated after the fact (a v_xor on the sign word each time: the FMA's output has no negation modifier).
+  TFHE_HD static void butterfly_inverse(elem u, elem v, elem w, elem& y0, elem& y1) {
+    const double dre = u.re - v.re, dim = u.im - v.im;
+    y0 = elem{u.re + v.re, u.im + v.im};
+    y1 = elem{__builtin_fma(dre, w.re, dim * w.im), __builtin_fma(dim, w.re, -(dre * w.im))};
+  }
+  // the low register windows' twiddles are read a transpose ahead of their pass (wave_ntt.h::PassTwiddles)
+  static constexpr bool kPreloadTwiddles = true;
   // a * (-conj(w)): the inverse butterfly's twiddle
   TFHE_HD static elem mul_inverse(elem a, elem w) {
     return elem{-__builtin_fma(a.re, w.re, a.im * w.im), __builtin_fma(a.re, w.im, -(a.im * w.re))};

@@ -38,9 +38,12 @@ struct GroupOf {
 // polynomial (8 elements per lane, one 6-wave team per CU: 137 ms per 1024 cfg5 bootstraps) and over four (4 elements
 // per lane, five register passes, 12 waves: 79.2 ms) but does not beat the 42-bit field's 77.2 ms -- a 12-wave team
 // is bound by its barriers, not its arithmetic (profiles/r02_kernel_ab.txt) -- so it is not instantiated.
+#ifndef TFHE_FFT_N2048
+#define TFHE_FFT_N2048 0
+#endif
 template <class F, int LOGN>
 constexpr bool field_shape_ok() {
-  return F::kLogShrink == 0 || LOGN == 10 || LOGN == 9;
+  return F::kLogShrink == 0 || LOGN == 10 || LOGN == 9 || (TFHE_FFT_N2048 && LOGN == 11);
 }
 
 // bytes of the twiddle table of a field at ring degree 2^LOGN
@@ -854,7 +857,9 @@ bool shape_supported_bmmp(u32 log_n, u32 k) { return log_n == 9 && (k == 1 || k 
 
 int field_parts(int field) { return (field == kFieldGoldilocks || field == kFieldFp49) ? 1 : 2; }
 
-bool field_shape_supported(int field, u32 log_n) { return field != kFieldFft || log_n == 9 || log_n == 10; }
+bool field_shape_supported(int field, u32 log_n) {
+  return field != kFieldFft || log_n == 9 || log_n == 10 || (TFHE_FFT_N2048 && log_n == 11);
+}
 
 // (field, log_n, k) -> template instantiation.  TFHE_DEV_CFG2_ONLY builds just the BASELINE cfg2
 // shape (N = 1024, k = 1) for fast iteration on the kernels.

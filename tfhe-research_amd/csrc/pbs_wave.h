@@ -60,6 +60,18 @@ TFHE_HD u32 round_value(u32 v, u32 ignored_bits) {
   return ((v >> ignored_bits) + ((v >> (ignored_bits - 1)) & 1u)) << ignored_bits;
 }
 
+// The same rounding with its two constants hoisted (both wave-uniform): half = 2^(ignored_bits - 1) and
+// keep = ~(2^ignored_bits - 1), or 0 and ~0 when nothing is ignored.  (v + half) & keep is the literal formula: with
+// v = q 2^ig + r the bit it adds is [r >= half], and both forms wrap to 0 mod 2^32 in the same case.  Two
+// instructions per coefficient instead of four and a select.
+struct RoundConsts {
+  u32 half, keep;
+};
+TFHE_HD RoundConsts round_consts(u32 ignored_bits) {
+  return ignored_bits == 0 ? RoundConsts{0u, ~0u} : RoundConsts{1u << (ignored_bits - 1), ~((1u << ignored_bits) - 1u)};
+}
+TFHE_HD u32 round_value_fast(u32 v, RoundConsts rc) { return (v + rc.half) & rc.keep; }
+
 // One limb of decomposer.rs:53-65.  `v` is already rounded.  Returns the digit as a wrapped u32
 // and updates the carry (0/1).  Limbs below first_shift are zero after rounding, so the chain can
 // start at first_shift with carry 0.
@@ -189,8 +201,9 @@ TFHE_HD void external_product_team_keys(const Ctx& c, const PbsParams& P, const 
   TopConsts<F, LT, G, true> ftop;
   if constexpr (TFHE_TOP_PREFETCH) ftop.issue(c.twiddles_uniform());
   u32 v[EC];
+  const RoundConsts rc = round_consts(P.ignored_bits);
 #pragma unroll
-  for (int r = 0; r < EC; ++r) v[r] = round_value(src(r * T + lane), P.ignored_bits);
+  for (int r = 0; r < EC; ++r) v[r] = round_value_fast(src(r * T + lane), rc);
   if constexpr (TFHE_TOP_PREFETCH) ftop.ready();
 
   // Key tiles of one level for my column: idx = s * PARTS + q, s = source polynomial 0..K, q = part.

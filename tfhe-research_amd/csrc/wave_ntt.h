@@ -41,6 +41,8 @@
 // and, for the team code in pbs_wave.h, int exchange_buffers() const (1 or 2 LDS buffers per group)
 // and Ctx with_exchange_buffer(int i) const (a copy whose scratch()/scratch_of() use buffer i).
 #pragma once
+#include <type_traits>
+
 #include "field_fft.h"
 #include "field_fp.h"
 #include "field_fp49.h"
@@ -380,11 +382,74 @@ TFHE_HD void ntt_transpose(const Ctx& c, typename F::elem (&x)[NttShape<LOGN, G>
   if (READS_CROSS) c.poly_sync(); else c.wave_sync();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Twiddles of a LOW register window, fetched ahead of the pass that uses them.
+// In the low windows every lane has its own twiddles (hi = tid >> LO differs), read from the working copy in LDS.
+// Left to the compiler each ds_read sits right in front of its butterfly -- the wave-level fences of the
+// transposes forbid hoisting it -- behind an s_waitcnt that exposes the LDS round trip: a dozen of them per pass
+// in the ISA of round 2's kernel.  PassTwiddles reads all of a pass's twiddles (1 + 2 + 4 for a three-bit window)
+// in one clump BEFORE the transpose that precedes the pass: the LDS pipe is in order per wave, so they arrive
+// before the transposed elements do, and the pass starts with every operand in registers.  Costs their registers
+// (28 VGPRs for 16-byte elements at e = 3) across the transpose, so a field opts in (F::kPreloadTwiddles): the
+// complex transform has them, the 8-byte fields at 16 elements per lane do not.
+// ---------------------------------------------------------------------------------------------
+#ifndef TFHE_PRELOAD_TWIDDLES
+#define TFHE_PRELOAD_TWIDDLES 1
+#endif
+template <class F, class = void>
+struct PreloadsTwiddles {
+  static constexpr bool value = false;
+};
+template <class F>
+struct PreloadsTwiddles<F, decltype((void)F::kPreloadTwiddles)> {
+  static constexpr bool value = F::kPreloadTwiddles && TFHE_PRELOAD_TWIDDLES != 0;
+};
+
+// position in the working copy of the twiddle that stage b of window [LO, LO+e) uses for register pair group i
+template <class F, int LOGN, int G, int LO, bool INVERSE>
+TFHE_HD int ntt_low_twiddle_slot(int tid, int b, int i) {
+  typedef typename F::elem elem;
+  constexpr int e = NttShape<LOGN, G>::kEBits;
+  constexpr int H = 1 << (NttShape<LOGN, G>::kTBits - LO);
+  const int hi = tid >> LO;
+  const int m = NttShape<LOGN, G>::kN >> (b + 1);
+  const int cnt = 1 << (LO + e - b - 1);
+  constexpr bool TR = ntt_twiddles_transposed<(int)sizeof(elem)>();
+  if (!INVERSE || F::kLogShrink) return TR ? m + i * H + hi : m + hi * cnt + i;  // node m + hi cnt + i
+  // prime fields, inverse: psi^-bitrev(m+j) = -psi_rev[2m-1-j]
+  return TR ? m + (cnt - 1 - i) * H + (H - 1 - hi) : 2 * m - 1 - hi * cnt - i;
+}
+
+template <class F, int LOGN, int G, int LO, int BHI, int BLO, bool INVERSE>
+struct PassTwiddles {
+  typedef typename F::elem elem;
+  static constexpr int E = NttShape<LOGN, G>::kE;
+  static constexpr int count_from(int b) { return b > BHI ? 0 : (E >> (b - LO + 1)) + count_from(b + 1); }
+  static constexpr int kCount = count_from(BLO);
+  // stage b's twiddles start behind those of the stages above it (b + 1 .. BHI)
+  static constexpr int offset(int b) { return count_from(b + 1); }
+  elem w[kCount];
+  template <class Ctx>
+  TFHE_HD void load(const Ctx& c) {
+    const elem* tw = c.twiddles();
+    const int tid = c.tid();
+#pragma unroll
+    for (int b = BHI; b >= BLO; --b)
+#pragma unroll
+      for (int i = 0; i < (E >> (b - LO + 1)); ++i) w[offset(b) + i] = tw[ntt_low_twiddle_slot<F, LOGN, G, LO, INVERSE>(tid, b, i)];
+  }
+  TFHE_HD elem get(int b, int i) const { return w[offset(b) + i]; }
+};
+// the pass reads its twiddles itself, one by one (fields that do not preload, and every top window)
+struct NoPassTwiddles {};
+
 // forward stages on bits BHI..BLO (descending) of window [LO, LO+e).  SMALL_FIRST: the inputs of
 // the first stage handled here are small integers (gadget digits), so its twiddle products may
 // use F::mul_small (exact without reduction in the fp64 field).
-template <class F, int LOGN, int G, int LO, int BHI, int BLO, bool SMALL_FIRST, class Ctx, class Top>
-TFHE_HD void ntt_pass_forward(const Ctx& c, typename F::elem (&x)[NttShape<LOGN, G>::kE], const Top& top) {
+template <class F, int LOGN, int G, int LO, int BHI, int BLO, bool SMALL_FIRST, class Ctx, class Top, class Pre = NoPassTwiddles>
+TFHE_HD void ntt_pass_forward(const Ctx& c, typename F::elem (&x)[NttShape<LOGN, G>::kE], const Top& top,
+                              const Pre& pre = Pre{}) {
+  constexpr bool PRE = !std::is_same<Pre, NoPassTwiddles>::value;
   typedef typename F::elem elem;
   constexpr int E = NttShape<LOGN, G>::kE;
   constexpr int e = NttShape<LOGN, G>::kEBits;
@@ -438,9 +503,11 @@ TFHE_HD void ntt_pass_forward(const Ctx& c, typename F::elem (&x)[NttShape<LOGN,
     for (int r0 = 0; r0 < E; ++r0) {
       if ((r0 >> rb) & 1) continue;
       const int r1 = r0 | (1 << rb);
-      const elem w = TOP ? top.tw(m + (r0 >> (rb + 1)))
-                     : ntt_twiddles_transposed<(int)sizeof(elem)>() ? tw[m + (r0 >> (rb + 1)) * H + hi]
-                                          : tw[m + (hi << (LO + e - b - 1)) + (r0 >> (rb + 1))];
+      elem w;
+      if constexpr (TOP) w = top.tw(m + (r0 >> (rb + 1)));
+      else if constexpr (PRE) w = pre.get(b, r0 >> (rb + 1));
+      else w = ntt_twiddles_transposed<(int)sizeof(elem)>() ? tw[m + (r0 >> (rb + 1)) * H + hi]
+                                                            : tw[m + (hi << (LO + e - b - 1)) + (r0 >> (rb + 1))];
       const elem u = x[r0];
       if constexpr (FusedForwardButterfly<F>::value) {
         // (u + w x1, u - w x1) in six fused multiply-adds instead of a product and two sums (field_fft.h)
@@ -455,8 +522,10 @@ TFHE_HD void ntt_pass_forward(const Ctx& c, typename F::elem (&x)[NttShape<LOGN,
 }
 
 // inverse stages on bits BLO..BHI (ascending) of window [LO, LO+e)
-template <class F, int LOGN, int G, int LO, int BHI, int BLO, class Ctx, class Top>
-TFHE_HD void ntt_pass_inverse(const Ctx& c, typename F::elem (&x)[NttShape<LOGN, G>::kE], const Top& top) {
+template <class F, int LOGN, int G, int LO, int BHI, int BLO, class Ctx, class Top, class Pre = NoPassTwiddles>
+TFHE_HD void ntt_pass_inverse(const Ctx& c, typename F::elem (&x)[NttShape<LOGN, G>::kE], const Top& top,
+                              const Pre& pre = Pre{}) {
+  constexpr bool PRE = !std::is_same<Pre, NoPassTwiddles>::value;
   typedef typename F::elem elem;
   constexpr int E = NttShape<LOGN, G>::kE;
   constexpr int e = NttShape<LOGN, G>::kEBits;
@@ -477,15 +546,21 @@ TFHE_HD void ntt_pass_inverse(const Ctx& c, typename F::elem (&x)[NttShape<LOGN,
       const int r1 = r0 | (1 << rb);
       // (F::inverse_twiddle_index(h, i) = 2h - 1 - i in the prime fields, h + i for the complex transform,
       // whose mul_inverse conjugates the entry)
-      const elem w = TOP ? top.tw(F::inverse_twiddle_index(h, r0 >> (rb + 1)))
-                     : ntt_twiddles_transposed<(int)sizeof(elem)>() ? (F::kLogShrink ? tw[h + (r0 >> (rb + 1)) * H + hi]  // node h + hi cnt + i
+      elem w;
+      if constexpr (TOP) w = top.tw(F::inverse_twiddle_index(h, r0 >> (rb + 1)));
+      else if constexpr (PRE) w = pre.get(b, r0 >> (rb + 1));
+      else w = ntt_twiddles_transposed<(int)sizeof(elem)>() ? (F::kLogShrink ? tw[h + (r0 >> (rb + 1)) * H + hi]  // node h + hi cnt + i
                                                            : tw[h + (cnt - 1 - (r0 >> (rb + 1))) * H + (H - 1 - hi)])
                                           : (F::kLogShrink ? tw[h + (hi << (LO + e - b - 1)) + (r0 >> (rb + 1))]
                                                            : tw[2 * h - 1 - (hi << (LO + e - b - 1)) - (r0 >> (rb + 1))]);
       const elem u = x[r0];
       const elem v = x[r1];
-      x[r0] = F::add(u, v);
-      x[r1] = F::mul_inverse(F::sub(v, u), w);
+      if constexpr (FusedForwardButterfly<F>::value) {
+        F::butterfly_inverse(u, v, w, x[r0], x[r1]);  // the same values without a negated result (field_fft.h)
+      } else {
+        x[r0] = F::add(u, v);
+        x[r1] = F::mul_inverse(F::sub(v, u), w);
+      }
     }
     // fields with little lazy headroom (F::kInverseSweepEvery > 0): the un-multiplied leg doubles
     // per stage, so everything is brought back to |.| <= p/2 after every kInverseSweepEvery-th stage
@@ -507,17 +582,41 @@ template <class F, int LOGN, int G, bool SMALL_INPUT = false, bool AFTER_BARRIER
 TFHE_HD void ntt_forward(const Ctx& c, typename F::elem (&x)[NttShape<LOGN, G>::kE], const Top& top) {
   using S = NttShape<LOGN, G>;
   ntt_pass_forward<F, LOGN, G, S::kLo1, LOGN - 1, S::kTBits, SMALL_INPUT>(c, x, top);
-  ntt_transpose<F, LOGN, G, S::kLo1, S::kLo2, AFTER_BARRIER>(c, x);
-  ntt_pass_forward<F, LOGN, G, S::kLo2, S::kTBits - 1, S::kLo2, false>(c, x, top);
-  ntt_transpose<F, LOGN, G, S::kLo2, S::kLo3>(c, x);
-  ntt_pass_forward<F, LOGN, G, S::kLo3, S::kLo2 - 1, S::kLo3, false>(c, x, top);
-  if constexpr (S::kPasses >= 4) {
-    ntt_transpose<F, LOGN, G, S::kLo3, S::kLo4>(c, x);
-    ntt_pass_forward<F, LOGN, G, S::kLo4, S::kLo3 - 1, S::kLo4, false>(c, x, top);
-  }
-  if constexpr (S::kPasses == 5) {
-    ntt_transpose<F, LOGN, G, S::kLo4, S::kLo5>(c, x);
-    ntt_pass_forward<F, LOGN, G, S::kLo5, S::kLo4 - 1, 0, false>(c, x, top);
+  if constexpr (PreloadsTwiddles<F>::value) {
+    // every low pass's twiddles are read before the transpose in front of it (PassTwiddles)
+    PassTwiddles<F, LOGN, G, S::kLo2, S::kTBits - 1, S::kLo2, false> t2;
+    t2.load(c);
+    ntt_transpose<F, LOGN, G, S::kLo1, S::kLo2, AFTER_BARRIER>(c, x);
+    ntt_pass_forward<F, LOGN, G, S::kLo2, S::kTBits - 1, S::kLo2, false>(c, x, top, t2);
+    PassTwiddles<F, LOGN, G, S::kLo3, S::kLo2 - 1, S::kLo3, false> t3;
+    t3.load(c);
+    ntt_transpose<F, LOGN, G, S::kLo2, S::kLo3>(c, x);
+    ntt_pass_forward<F, LOGN, G, S::kLo3, S::kLo2 - 1, S::kLo3, false>(c, x, top, t3);
+    if constexpr (S::kPasses >= 4) {
+      PassTwiddles<F, LOGN, G, S::kLo4, S::kLo3 - 1, S::kLo4, false> t4;
+      t4.load(c);
+      ntt_transpose<F, LOGN, G, S::kLo3, S::kLo4>(c, x);
+      ntt_pass_forward<F, LOGN, G, S::kLo4, S::kLo3 - 1, S::kLo4, false>(c, x, top, t4);
+    }
+    if constexpr (S::kPasses == 5) {
+      PassTwiddles<F, LOGN, G, S::kLo5, S::kLo4 - 1, 0, false> t5;
+      t5.load(c);
+      ntt_transpose<F, LOGN, G, S::kLo4, S::kLo5>(c, x);
+      ntt_pass_forward<F, LOGN, G, S::kLo5, S::kLo4 - 1, 0, false>(c, x, top, t5);
+    }
+  } else {
+    ntt_transpose<F, LOGN, G, S::kLo1, S::kLo2, AFTER_BARRIER>(c, x);
+    ntt_pass_forward<F, LOGN, G, S::kLo2, S::kTBits - 1, S::kLo2, false>(c, x, top);
+    ntt_transpose<F, LOGN, G, S::kLo2, S::kLo3>(c, x);
+    ntt_pass_forward<F, LOGN, G, S::kLo3, S::kLo2 - 1, S::kLo3, false>(c, x, top);
+    if constexpr (S::kPasses >= 4) {
+      ntt_transpose<F, LOGN, G, S::kLo3, S::kLo4>(c, x);
+      ntt_pass_forward<F, LOGN, G, S::kLo4, S::kLo3 - 1, S::kLo4, false>(c, x, top);
+    }
+    if constexpr (S::kPasses == 5) {
+      ntt_transpose<F, LOGN, G, S::kLo4, S::kLo5>(c, x);
+      ntt_pass_forward<F, LOGN, G, S::kLo5, S::kLo4 - 1, 0, false>(c, x, top);
+    }
   }
 }
 
@@ -532,19 +631,45 @@ TFHE_HD void ntt_forward(const Ctx& c, typename F::elem (&x)[NttShape<LOGN, G>::
 template <class F, int LOGN, int G, class Ctx, class Top>
 TFHE_HD void ntt_inverse(const Ctx& c, typename F::elem (&x)[NttShape<LOGN, G>::kE], const Top& top) {
   using S = NttShape<LOGN, G>;
-  if constexpr (S::kPasses == 5) {
-    ntt_pass_inverse<F, LOGN, G, S::kLo5, S::kLo4 - 1, 0>(c, x, top);
-    ntt_transpose<F, LOGN, G, S::kLo5, S::kLo4>(c, x);
+  if constexpr (PreloadsTwiddles<F>::value) {
+    // the first pass's twiddles are read on entry (nothing to hide them behind but the caller's last instructions),
+    // every later low pass's before the transpose in front of it
+    if constexpr (S::kPasses == 5) {
+      PassTwiddles<F, LOGN, G, S::kLo5, S::kLo4 - 1, 0, true> t5;
+      t5.load(c);
+      ntt_pass_inverse<F, LOGN, G, S::kLo5, S::kLo4 - 1, 0>(c, x, top, t5);
+    }
+    if constexpr (S::kPasses >= 4) {
+      PassTwiddles<F, LOGN, G, S::kLo4, S::kLo3 - 1, S::kLo4, true> t4;
+      t4.load(c);
+      if constexpr (S::kPasses == 5) ntt_transpose<F, LOGN, G, S::kLo5, S::kLo4>(c, x);
+      ntt_pass_inverse<F, LOGN, G, S::kLo4, S::kLo3 - 1, S::kLo4>(c, x, top, t4);
+    }
+    PassTwiddles<F, LOGN, G, S::kLo3, S::kLo2 - 1, S::kLo3, true> t3;
+    t3.load(c);
+    if constexpr (S::kPasses >= 4) ntt_transpose<F, LOGN, G, S::kLo4, S::kLo3>(c, x);
+    ntt_pass_inverse<F, LOGN, G, S::kLo3, S::kLo2 - 1, S::kLo3>(c, x, top, t3);
+    PassTwiddles<F, LOGN, G, S::kLo2, S::kTBits - 1, S::kLo2, true> t2;
+    t2.load(c);
+    ntt_transpose<F, LOGN, G, S::kLo3, S::kLo2>(c, x);
+    ntt_pass_inverse<F, LOGN, G, S::kLo2, S::kTBits - 1, S::kLo2>(c, x, top, t2);
+    ntt_transpose<F, LOGN, G, S::kLo2, S::kLo1>(c, x);
+    ntt_pass_inverse<F, LOGN, G, S::kLo1, LOGN - 1, S::kTBits>(c, x, top);
+  } else {
+    if constexpr (S::kPasses == 5) {
+      ntt_pass_inverse<F, LOGN, G, S::kLo5, S::kLo4 - 1, 0>(c, x, top);
+      ntt_transpose<F, LOGN, G, S::kLo5, S::kLo4>(c, x);
+    }
+    if constexpr (S::kPasses >= 4) {
+      ntt_pass_inverse<F, LOGN, G, S::kLo4, S::kLo3 - 1, S::kLo4>(c, x, top);
+      ntt_transpose<F, LOGN, G, S::kLo4, S::kLo3>(c, x);
+    }
+    ntt_pass_inverse<F, LOGN, G, S::kLo3, S::kLo2 - 1, S::kLo3>(c, x, top);
+    ntt_transpose<F, LOGN, G, S::kLo3, S::kLo2>(c, x);
+    ntt_pass_inverse<F, LOGN, G, S::kLo2, S::kTBits - 1, S::kLo2>(c, x, top);
+    ntt_transpose<F, LOGN, G, S::kLo2, S::kLo1>(c, x);
+    ntt_pass_inverse<F, LOGN, G, S::kLo1, LOGN - 1, S::kTBits>(c, x, top);
   }
-  if constexpr (S::kPasses >= 4) {
-    ntt_pass_inverse<F, LOGN, G, S::kLo4, S::kLo3 - 1, S::kLo4>(c, x, top);
-    ntt_transpose<F, LOGN, G, S::kLo4, S::kLo3>(c, x);
-  }
-  ntt_pass_inverse<F, LOGN, G, S::kLo3, S::kLo2 - 1, S::kLo3>(c, x, top);
-  ntt_transpose<F, LOGN, G, S::kLo3, S::kLo2>(c, x);
-  ntt_pass_inverse<F, LOGN, G, S::kLo2, S::kTBits - 1, S::kLo2>(c, x, top);
-  ntt_transpose<F, LOGN, G, S::kLo2, S::kLo1>(c, x);
-  ntt_pass_inverse<F, LOGN, G, S::kLo1, LOGN - 1, S::kTBits>(c, x, top);
 }
 
 template <class F, int LOGN, int G, class Ctx>
