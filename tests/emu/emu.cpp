@@ -21,12 +21,13 @@ using namespace tfhe;
 namespace {
 
 int g_exchange_buffers = 1;  // exchange buffers per group (kernels.hip::ExchangeBuffersOf)
+int g_samples_per_team = 1;  // samples a team rotates at once (kernels.hip::SamplesPerTeam): each needs a buffer and an accumulator
 
 template <class Elem>
 struct HostTeam {
   int n, g;  // ring degree, waves per polynomial group
   int ns;    // transform elements per polynomial (n, or n/2 for the complex transform)
-  int exb, groups;
+  int exb, groups, samples;
   std::vector<Elem> scratch, tw, tw_natural;
   std::vector<u32> acc;
   pthread_barrier_t team_bar;
@@ -52,7 +53,7 @@ struct HostWave {
   void team_sync() const { pthread_barrier_wait(&t_->team_bar); }
   Elem* scratch() const { return t_->scratch.data() + ((size_t)buf_ * t_->groups + group()) * t_->ns; }
   const Elem* scratch_of(int s) const { return t_->scratch.data() + ((size_t)buf_ * t_->groups + s) * t_->ns; }
-  u32* acc() const { return t_->acc.data() + (size_t)group() * t_->n; }
+  u32* acc(int s = 0) const { return t_->acc.data() + ((size_t)group() * t_->samples + s) * t_->n; }
   const Elem* twiddles() const { return t_->tw.data(); }
   const Elem* twiddles_uniform() const { return t_->tw_natural.data(); }
   u32 uniform(u32 v) const { return v; }
@@ -66,12 +67,13 @@ void run_team(int logn, int groups, int g, const std::function<void(const HostWa
   HostTeam<elem> team;
   team.n = 1 << logn;
   team.g = g;
-  team.exb = g_exchange_buffers;
+  team.samples = g_samples_per_team;
+  team.exb = g_exchange_buffers > team.samples ? g_exchange_buffers : team.samples;
   team.groups = groups;
   const int lt = logn - F::kLogShrink;  // log2 of the transform size
   team.ns = 1 << lt;
   team.scratch.resize((size_t)groups * team.ns * team.exb);
-  team.acc.resize((size_t)groups * team.n);
+  team.acc.resize((size_t)groups * team.samples * team.n);
   // natural-order table -> the working copy's layout, as the kernels stage it into LDS
   std::vector<elem>& natural = team.tw_natural;
   natural.resize(ntt_twiddle_words(team.ns));
@@ -148,7 +150,7 @@ void bsk_prepare(size_t polys, const u32* src, typename F::elem* dst) {
   }
 }
 
-template <class F, int LOGN, int K, int G>
+template <class F, int LOGN, int K, int G, int NS = 1>
 void blind_rotate(const PbsParams& P, size_t batch, const u32* lwe, const u32* tv, size_t tv_stride,
                   const typename F::elem* bsk, u32* out_glwe, u32* out_lwe) {
   typedef typename F::elem elem;
@@ -158,12 +160,24 @@ void blind_rotate(const PbsParams& P, size_t batch, const u32* lwe, const u32* t
   if constexpr (!shape_ok<F, LOGN, G>()) std::abort();
   else
   run_team<F>(LOGN, K + 1, G, [&](const HostWave<elem>& w) {
-    for (size_t b = 0; b < batch; ++b) {
-      blind_rotate_team<F, LOGN, K, G>(w, P, lwe + b * (P.n + 1), tv + b * tv_stride, bsk);
-      if (out_glwe)
-        for (int r = 0; r < E; ++r)
-          out_glwe[(b * (K + 1) + w.group()) * N + r * T + w.tid()] = w.acc()[r * T + w.tid()];
-      if (out_lwe) sample_extract_team<LOGN, K, G>(w, out_lwe + b * ((size_t)K * N + 1));
+    // teams of NS samples, as blind_rotate_kernel forms them: an odd batch's last team redoes its last sample
+    for (size_t b0 = 0; b0 < batch; b0 += NS) {
+      size_t idx[NS];
+      const u32* lwes[NS];
+      const u32* tvs[NS];
+      for (int s = 0; s < NS; ++s) {
+        idx[s] = b0 + s < batch ? b0 + s : batch - 1;
+        lwes[s] = lwe + idx[s] * (P.n + 1);
+        tvs[s] = tv + idx[s] * tv_stride;
+      }
+      blind_rotate_team_multi<F, LOGN, K, G, NS>(w, P, lwes, tvs, bsk);
+      for (int s = 0; s < NS && b0 + s < batch; ++s) {
+        const size_t b = idx[s];
+        if (out_glwe)
+          for (int r = 0; r < E; ++r)
+            out_glwe[(b * (K + 1) + w.group()) * N + r * T + w.tid()] = w.acc(s)[r * T + w.tid()];
+        if (out_lwe) sample_extract_team<LOGN, K, G>(w, out_lwe + b * ((size_t)K * N + 1), s);
+      }
       w.team_sync();
     }
   });
@@ -265,6 +279,7 @@ extern "C" {
 
 void emu_set_aligned(int aligned) { g_aligned = aligned != 0; }
 void emu_set_exchange_buffers(int n) { g_exchange_buffers = n == 2 ? 2 : 1; }
+void emu_set_samples_per_team(int n) { g_samples_per_team = n == 2 ? 2 : 1; }
 int emu_field_parts(int field) { return (field == 1 || field == 4) ? 1 : 2; }
 // 1 if the emulator can run `field` at ring degree 2^logn with g waves per polynomial
 int emu_field_shape_ok(int field, int logn, int g) {
@@ -336,6 +351,14 @@ int emu_blind_rotate(int field, int g, u32 n, u32 k, u32 logn, u32 log_p, u32 pa
                      u32 levels, size_t batch, const u32* lwe, const u32* tv, size_t tv_stride,
                      const void* bsk, u32* out_glwe, u32* out_lwe) {
   PbsParams P = make_params(n, k, logn, log_p, padding, log_base, levels);
+  if (g_samples_per_team == 2) {  // two samples per team (emu_set_samples_per_team): the complex transform's kernels use it
+    if (field != 5) return 4;
+    typedef FftField FF;
+    if (k == 1) { DISPATCH_LOGN(logn, g, (blind_rotate<FF, L, 1, GG, 2>(P, batch, lwe, tv, tv_stride, (const FF::elem*)bsk, out_glwe, out_lwe))); }
+    else if (k == 2) { DISPATCH_LOGN(logn, g, (blind_rotate<FF, L, 2, GG, 2>(P, batch, lwe, tv, tv_stride, (const FF::elem*)bsk, out_glwe, out_lwe))); }
+    else return 2;
+    return 0;
+  }
   if (k == 1) { DISPATCH_FIELD(field, DISPATCH_LOGN(logn, g, (blind_rotate<FF, L, 1, GG>(P, batch, lwe, tv, tv_stride, (const FF::elem*)bsk, out_glwe, out_lwe)))); }
   else if (k == 2) { DISPATCH_FIELD(field, DISPATCH_LOGN(logn, g, (blind_rotate<FF, L, 2, GG>(P, batch, lwe, tv, tv_stride, (const FF::elem*)bsk, out_glwe, out_lwe)))); }
   else return 2;

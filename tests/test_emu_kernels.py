@@ -401,6 +401,37 @@ def test_blind_rotate_and_extract_vs_oracle(emu, oracle, exchange_buffers, field
         assert np.array_equal(ext[b], tr["extracted_lwe"]), f"sample {b}"
 
 
+@pytest.mark.parametrize("k,logn,n,pbs,log_p,g", [(1, 9, 5, (8, 2), 2, 1), (2, 9, 4, (4, 6), 2, 1), (1, 10, 3, (8, 4), 2, 1),
+                                                  (2, 11, 3, (8, 4), 4, 4)])
+def test_two_samples_per_team_vs_oracle(emu, oracle, k, logn, n, pbs, log_p, g):
+    """pbs_wave.h::blind_rotate_team_multi with NS = 2 (the complex transform's kernels at N = 512, k = 2 and N = 2048):
+    a team rotates two samples at once -- one key fetch, one set of barriers, the inverse transforms in lockstep -- and
+    every sample must come out as if it had been alone.  Odd batch (3): the last team redoes its last sample in the
+    free slot and writes it once; per-sample test vectors; a~ = 0 and b~ -> 2N rows included."""
+    params = oracle.Params(k, logn, n, oracle.Decomposer(*pbs), log_p=log_p)
+    batch = 3
+    lwe, bsk, ksk, _ = oracle.synthetic_inputs(params, batch, cfg_index=70 + logn)
+    rng = np.random.default_rng(logn * 3 + k)
+    tvs = rng.integers(0, 1 << log_p, size=(batch, params.N)).astype(np.uint32)
+    lwe = lwe.copy()
+    lwe[0, 0] = 0
+    lwe[1, n] = 0xFFFFFFFF
+    spec = prepared(emu, FFT, params, bsk, g)
+    glwe = np.zeros((batch, k + 1, params.N), dtype=np.uint32)
+    ext = np.zeros((batch, params.big_n + 1), dtype=np.uint32)
+    emu.emu_set_samples_per_team(2)
+    try:
+        rc = emu.emu_blind_rotate(FFT, g, n, k, logn, log_p, 1, pbs[0], pbs[1], C.c_size_t(batch), p32(lwe), p32(tvs),
+                                  C.c_size_t(params.N), p64(spec), p32(glwe), p32(ext))
+    finally:
+        emu.emu_set_samples_per_team(1)
+    assert rc == 0
+    for b in range(batch):
+        _, tr = oracle.bootstrap(params, lwe[b], bsk, ksk, tvs[b], trace=True)
+        assert np.array_equal(glwe[b], tr["acc_final"]), f"sample {b}"
+        assert np.array_equal(ext[b], tr["extracted_lwe"]), f"sample {b}"
+
+
 @pytest.mark.parametrize("k,logn,n,pbs,log_p,g,exb", CASES_P49)
 def test_fp49_field_more_shapes(emu, oracle, k, logn, n, pbs, log_p, g, exb):
     """external product and blind rotation + sample extract in the 49-bit single-spectrum field"""

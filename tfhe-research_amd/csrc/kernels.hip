@@ -51,6 +51,13 @@ template <class F, int LOGN>
 constexpr size_t twiddle_bytes() {
   return (size_t)ntt_twiddle_words(1 << (LOGN - F::kLogShrink)) * sizeof(typename F::elem);
 }
+// entries of it the working copy in LDS needs: the fused-stage constants behind psi_rev[N) are read through the
+// uniform pointer only, and fields without fused stages do not have them at all -- 288 bytes that decide whether
+// a fourth team fits a CU at N = 512, k = 2 and whether two samples fit the one team of N = 2048
+template <class F, int LOGN>
+constexpr int staged_twiddle_words() {
+  return F::kFuseFirstTwo ? ntt_twiddle_words(1 << (LOGN - F::kLogShrink)) : (1 << (LOGN - F::kLogShrink));
+}
 
 template <class Elem, int G, int EXB = 1>
 struct DeviceWave {
@@ -62,6 +69,7 @@ struct DeviceWave {
   int group_;                 // polynomial / output column of my group
   unsigned group_stride_;     // bytes of LDS per group
   unsigned buffer_bytes_;     // bytes of one exchange buffer (EXB of them per group, back to back)
+  unsigned acc_words_;        // u32 words of one accumulator polynomial (one per sample of the team, back to back)
   // number of exchange buffers per group and a copy of this context that works in buffer i
   // (pbs_wave.h::external_product_team); buffer 0 is the one selected at construction
   __device__ __forceinline__ int exchange_buffers() const { return EXB; }
@@ -106,7 +114,7 @@ struct DeviceWave {
   __device__ __forceinline__ const Elem* scratch_of(int s) const {
     return reinterpret_cast<const Elem*>(team_base_ + (size_t)s * group_stride_);
   }
-  __device__ __forceinline__ u32* acc() const { return acc_; }
+  __device__ __forceinline__ u32* acc(int s = 0) const { return acc_ + (size_t)s * acc_words_; }
   __device__ __forceinline__ const Elem* twiddles() const { return tw_; }
   __device__ __forceinline__ const Elem* twiddles_uniform() const { return twg_; }
   __device__ __forceinline__ u32 uniform(u32 v) const { return __builtin_amdgcn_readfirstlane(v); }
@@ -140,34 +148,53 @@ struct ExchangeBuffersOf {
 // a key tile finding it in the CU's vector L1 -- were measured for the complex transform, whose kernel draws
 // 13 TB/s of key from L2: 41.5 and 46.4 ms against 37.1 ms with one team per workgroup.  Teams that are free
 // to drift fill each other's stalls; coupling them costs more than the L1 hits give.)
+// Samples per team in the blind rotation (pbs_wave.h::external_product_team_multi): two where the registers allow it
+// (the complex transform with 4 elements per lane) AND the kernel waits on its key stream or its barriers -- the
+// twelve-wave team of N = 2048 and the many digit rows of N = 512, k = 2.  Measured per shape, profiles/r03_kernel_ab.txt.
+#ifndef TFHE_NS_N2048
+#define TFHE_NS_N2048 2
+#endif
+#ifndef TFHE_NS_N512_K2
+#define TFHE_NS_N512_K2 2
+#endif
+#ifndef TFHE_NS_N512_K1
+#define TFHE_NS_N512_K1 1
+#endif
 template <class F, int LOGN, int K>
+struct SamplesPerTeam {
+  static constexpr int value = !F::kLogShrink ? 1 : LOGN == 11 ? TFHE_NS_N2048 : LOGN == 9 ? (K == 2 ? TFHE_NS_N512_K2 : TFHE_NS_N512_K1) : 1;
+};
+
+template <class F, int LOGN, int K, int NS_ = SamplesPerTeam<F, LOGN, K>::value>
 struct TeamCfg {
   static constexpr int N = 1 << LOGN;
   static constexpr int G = GroupOf<F, LOGN>::value;
-  static constexpr int EXB = ExchangeBuffersOf<LOGN>::value;
+  static constexpr int S = NS_;  // samples per team: each has an exchange buffer and an accumulator per group
+  static constexpr int EXB = ExchangeBuffersOf<LOGN>::value > S ? ExchangeBuffersOf<LOGN>::value : S;
   static constexpr int kWaves = (K + 1) * G;
   static constexpr int kThreads = kWaves * 64;
-  static constexpr unsigned kGroupLds = (unsigned)N * 8u * EXB + (unsigned)N * 4u;
-  // room for the largest table: (N + 18) 8-byte elements or (N/2 + 18) 16-byte ones
-  static constexpr size_t kTwBytes = (size_t)N * 8 + 18 * 16;  // multiple of 16
+  static constexpr unsigned kGroupLds = (unsigned)N * 8u * EXB + (unsigned)N * 4u * S;
+  // the working copy of the table: (N + 18) 8-byte elements, or N/2 16-byte ones
+  static constexpr size_t kTwBytes = (size_t)staged_twiddle_words<F, LOGN>() * sizeof(typename F::elem);  // multiple of 16
   static constexpr size_t kLds = kTwBytes + (size_t)(K + 1) * kGroupLds;
   static constexpr int kMinWavesGl = (NttShape<LOGN, G>::kE == 8) ? TFHE_WAVES_PER_SIMD_E8 : TFHE_WAVES_PER_SIMD_GL;
   static constexpr int kMinWavesFp = (NttShape<LOGN, G>::kE == 8) ? TFHE_WAVES_PER_SIMD_E8 : TFHE_WAVES_PER_SIMD_FP;
 };
 
-template <class F, int LOGN, int K>
-__device__ __forceinline__ DeviceWave<typename F::elem, GroupOf<F, LOGN>::value, ExchangeBuffersOf<LOGN>::value>
+template <class F, int LOGN, int K, int NS = SamplesPerTeam<F, LOGN, K>::value>
+__device__ __forceinline__ DeviceWave<typename F::elem, GroupOf<F, LOGN>::value, TeamCfg<F, LOGN, K, NS>::EXB>
 make_wave(unsigned char* smem, const typename F::elem* tw_global) {
   typedef typename F::elem elem;
-  using C = TeamCfg<F, LOGN, K>;
-  static_assert(twiddle_bytes<F, LOGN>() <= C::kTwBytes, "twiddle table");
+  using C = TeamCfg<F, LOGN, K, NS>;
+  static_assert(C::kTwBytes % 16 == 0, "twiddle table");
   elem* tw = reinterpret_cast<elem*>(smem);
-  ntt_stage_twiddles<LOGN - F::kLogShrink, C::G>(tw, tw_global, (int)threadIdx.x, (int)blockDim.x);
+  ntt_stage_twiddles<LOGN - F::kLogShrink, C::G, elem, staged_twiddle_words<F, LOGN>()>(tw, tw_global, (int)threadIdx.x, (int)blockDim.x);
   __syncthreads();
   DeviceWave<elem, C::G, C::EXB> w;
   w.group_ = (int)(threadIdx.x / (64u * C::G));
   w.group_stride_ = C::kGroupLds;
   w.buffer_bytes_ = (unsigned)C::N * 8u;
+  w.acc_words_ = (unsigned)C::N;
   w.team_base_ = smem + C::kTwBytes;
   unsigned char* base = w.team_base_ + (size_t)w.group_ * C::kGroupLds;
   w.tw_ = tw;
@@ -206,6 +233,7 @@ __global__ void __launch_bounds__(256) bsk_prepare_kernel(const typename F::elem
   w.group_ = 0;
   w.group_stride_ = 0;
   w.buffer_bytes_ = 0;
+  w.acc_words_ = 0;
   w.team_base_ = nullptr;
   w.tw_ = twl;
   w.twg_ = tw;
@@ -227,20 +255,36 @@ blind_rotate_kernel(PbsParams P, const typename F::elem* __restrict__ tw,
   using C = TeamCfg<F, LOGN, K>;
   constexpr int N = C::N;
   constexpr int G = C::G;
+  constexpr int NS = C::S;
   constexpr int E = NttShape<LOGN, G>::kE;
   constexpr int T = NttShape<LOGN, G>::kThreads;
   auto w = make_wave<F, LOGN, K>(g_smem, tw);
-  const size_t sample = blockIdx.x;  // grid = batch: no ragged tail, every wave runs every barrier
+  // grid = ceil(batch / NS) teams of NS samples; every wave runs every barrier.  An odd batch leaves the last team
+  // one sample short: it redoes the last sample in the free slot (same inputs, no output)
+  size_t sample[NS];
+  const u32* lwes[NS];
+  const u32* tvs[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const size_t idx = (size_t)blockIdx.x * NS + s;
+    sample[s] = idx < batch ? idx : batch - 1;
+    lwes[s] = lwe_in + sample[s] * (P.n + 1);
+    tvs[s] = tv + sample[s] * tv_stride;
+  }
 
-  blind_rotate_team<F, LOGN, K, G>(w, P, lwe_in + sample * (P.n + 1), tv + sample * tv_stride, bsk);
+  blind_rotate_team_multi<F, LOGN, K, G, NS>(w, P, lwes, tvs, bsk);
 
   const int tid = w.tid();
-  if (glwe_out) {
-    u32* dst = glwe_out + (sample * (size_t)(K + 1) + w.group()) * N;
 #pragma unroll
-    for (int r = 0; r < E; ++r) dst[r * T + tid] = w.acc()[r * T + tid];
+  for (int s = 0; s < NS; ++s) {
+    if ((size_t)blockIdx.x * NS + s >= batch) break;  // the duplicate of an odd batch's last sample
+    if (glwe_out) {
+      u32* dst = glwe_out + (sample[s] * (size_t)(K + 1) + w.group()) * N;
+#pragma unroll
+      for (int r = 0; r < E; ++r) dst[r * T + tid] = w.acc(s)[r * T + tid];
+    }
+    if (lwe_extracted) sample_extract_team<LOGN, K, G>(w, lwe_extracted + sample[s] * ((size_t)K * N + 1), s);
   }
-  if (lwe_extracted) sample_extract_team<LOGN, K, G>(w, lwe_extracted + sample * ((size_t)K * N + 1));
 }
 
 // unrolled blind rotation (two key bits per step, pbs_wave.h::blind_rotate_bmmp_team); offered where a
@@ -249,18 +293,18 @@ blind_rotate_kernel(PbsParams P, const typename F::elem* __restrict__ tw,
 #define TFHE_BMMP_MIN_WAVES 3
 #endif
 template <class F, int LOGN, int K>
-__global__ void __launch_bounds__((TeamCfg<F, LOGN, K>::kThreads), TFHE_BMMP_MIN_WAVES)
+__global__ void __launch_bounds__((TeamCfg<F, LOGN, K, 1>::kThreads), TFHE_BMMP_MIN_WAVES)
 blind_rotate_bmmp_kernel(PbsParams P, const typename F::elem* __restrict__ tw,
                          const u32* __restrict__ lwe_in, size_t batch, const u32* __restrict__ tv,
                          size_t tv_stride, const typename F::elem* __restrict__ bsk,
                          u32* __restrict__ glwe_out, u32* __restrict__ lwe_extracted) {
-  using C = TeamCfg<F, LOGN, K>;
+  using C = TeamCfg<F, LOGN, K, 1>;
   constexpr int N = C::N;
   constexpr int G = C::G;
   constexpr int E = NttShape<LOGN, G>::kE;
   constexpr int T = NttShape<LOGN, G>::kThreads;
   static_assert(G == 1 && C::EXB == 1, "one wave per polynomial, one exchange buffer");
-  auto w = make_wave<F, LOGN, K>(g_smem, tw);
+  auto w = make_wave<F, LOGN, K, 1>(g_smem, tw);
   const size_t sample = blockIdx.x;
   blind_rotate_bmmp_team<F, LOGN, K, G>(w, P, lwe_in + sample * (P.n + 1), tv + sample * tv_stride, bsk);
   const int tid = w.tid();
@@ -292,16 +336,16 @@ blind_rotate_bmmp_kernel(PbsParams P, const typename F::elem* __restrict__ tw,
 template <class F, int LOGN, int K>
 __global__ void __launch_bounds__((TeamCfg<F, LOGN, K>::kThreads),
                                   (F::kId == FpField::kId || F::kId == Fp49Field::kId || F::kId == FftField::kId
-                                       ? TeamCfg<F, LOGN, K>::kMinWavesFp
-                                       : TeamCfg<F, LOGN, K>::kMinWavesGl))
+                                       ? TeamCfg<F, LOGN, K, 1>::kMinWavesFp
+                                       : TeamCfg<F, LOGN, K, 1>::kMinWavesGl))
 external_product_kernel(PbsParams P, const typename F::elem* __restrict__ tw,
                         const typename F::elem* __restrict__ ggsw, size_t ggsw_stride_words,
                         const u32* glwe_in, u32* ct1_inout, const u32* cmux_ct0, size_t batch,
                         u32* glwe_out, unsigned long long* queue /* null: by stride */) {
-  using C = TeamCfg<F, LOGN, K>;
+  using C = TeamCfg<F, LOGN, K, 1>;  // one product per team at a time (the samples have their own GGSWs in general)
   constexpr int N = C::N;
   constexpr int G = C::G;
-  auto w = make_wave<F, LOGN, K>(g_smem, tw);
+  auto w = make_wave<F, LOGN, K, 1>(g_smem, tw);
   const bool is_cmux = cmux_ct0 != nullptr;
   // the ticket of the team's current sample, published through LDS (behind the team's arrays)
   unsigned long long* ticket = reinterpret_cast<unsigned long long*>(g_smem + C::kLds);
@@ -595,6 +639,7 @@ __global__ void __launch_bounds__(256) glwe_body_kernel(const typename F::elem* 
   w.group_ = 0;
   w.group_stride_ = 0;
   w.buffer_bytes_ = 0;
+  w.acc_words_ = 0;
   w.team_base_ = nullptr;
   w.tw_ = twl;
   w.twg_ = tw;
@@ -731,7 +776,7 @@ hipError_t launch_blind_rotate(hipStream_t s, const PbsParams& P, const void* tw
     const size_t chunk = blind_rotate_chunk<F>();
     for (size_t off = 0; off < batch; off += chunk) {
       const size_t here = batch - off < chunk ? batch - off : chunk;
-      hipLaunchKernelGGL(kern, dim3((unsigned)here), dim3(C::kThreads), C::kLds, s, P, tw,
+      hipLaunchKernelGGL(kern, dim3((unsigned)((here + C::S - 1) / C::S)), dim3(C::kThreads), C::kLds, s, P, tw,
                          lwe_in + off * ((size_t)P.n + 1), here, tv + off * tv_stride, tv_stride, bsk,
                          glwe_out ? glwe_out + off * (size_t)(K + 1) * C::N : nullptr,
                          lwe_extracted ? lwe_extracted + off * ((size_t)K * C::N + 1) : nullptr);
@@ -749,7 +794,7 @@ hipError_t launch_blind_rotate_bmmp(hipStream_t s, const PbsParams& P, const voi
   if constexpr (LOGN != 9 || !field_shape_ok<F, LOGN>()) {
     return hipErrorInvalidValue;  // shape_supported_bmmp() keeps callers away
   } else {
-    using C = TeamCfg<F, LOGN, K>;
+    using C = TeamCfg<F, LOGN, K, 1>;
     auto tw = static_cast<const typename F::elem*>(tw_v);
     auto bsk = static_cast<const typename F::elem*>(bsk_v);
     auto kern = blind_rotate_bmmp_kernel<F, LOGN, K>;
@@ -770,7 +815,7 @@ hipError_t launch_external_product(hipStream_t s, const PbsParams& P, const void
   if constexpr (!field_shape_ok<F, LOGN>()) {
     return hipErrorInvalidValue;
   } else {
-    using C = TeamCfg<F, LOGN, K>;
+    using C = TeamCfg<F, LOGN, K, 1>;
     constexpr size_t kLdsWithTicket = C::kLds + 16;
     auto tw = static_cast<const typename F::elem*>(tw_v);
     auto ggsw = static_cast<const typename F::elem*>(ggsw_v);

@@ -160,10 +160,18 @@ TFHE_HD u32 monomial_coeff(const u32* poly, int j, u32 m) {
 #ifndef TFHE_TOP_PREFETCH
 #define TFHE_TOP_PREFETCH 1
 #endif
-template <class F, int LOGN, int K, int G, int KEYS, class Ctx, class Src, class Out, class EndKey>
-TFHE_HD void external_product_team_keys(const Ctx& c, const PbsParams& P, const typename F::elem* ggsw,
-                                        size_t ggsw_words, Src src, Out out, EndKey end_of_key) {
+// NS > 1: the team multiplies NS GLWE operands (NS independent samples of a batch) with the SAME prepared GGSW in
+// one pass.  Every key chunk is fetched from L2 once and used NS times, the NS transforms of a step run in lockstep
+// through one set of transposes and barriers (ntt_forward_multi), and a team barrier covers NS products instead
+// of one -- the kernels whose waves wait on the key stream and on each other (twelve-wave teams at N = 2048; many
+// digit rows at N = 512) spend half as much of both per product.  Sample s works in exchange buffer s
+// (Ctx::with_exchange_buffer) and has its own accumulators; src(s, j) / out(m, s, j, value) name the sample.
+// KEYS > 1 (the unrolled blind rotation) keeps NS = 1.
+template <class F, int LOGN, int K, int G, int KEYS, int NS, class Ctx, class Src, class Out, class EndKey>
+TFHE_HD void external_product_team_multi(const Ctx& c, const PbsParams& P, const typename F::elem* ggsw,
+                                         size_t ggsw_words, Src src, Out out, EndKey end_of_key) {
   typedef typename F::elem elem;
+  static_assert(KEYS == 1 || NS == 1, "several keys or several samples, not both");
   // LT: log2 of the transform size -- the ring degree in the prime fields, half of it for the complex
   // transform, whose elements hold the coefficient pairs (j, j + N/2) (field_fft.h).  A lane holds E
   // transform elements and EC = E * F::kCoeffs ring coefficients per array; element r of a lane pairs the
@@ -178,32 +186,36 @@ TFHE_HD void external_product_team_keys(const Ctx& c, const PbsParams& P, const 
   constexpr int PARTS = F::kParts;
   const int lane = c.tid();   // thread index inside my polynomial's group of G waves
   const int me = c.group();   // polynomial / output column owned by my group
-  // (h, l) accumulator pairs only for a single key: with several keys the second set does not fit
-  constexpr bool SPLIT = F::template split_accum<E>() && KEYS == 1;
-  constexpr int ACCS = KEYS * PARTS;  // accumulator a = m * PARTS + q: key m, key part q
+  // (h, l) accumulator pairs only for a single key and sample: a second set per accumulator does not fit otherwise
+  constexpr bool SPLIT = F::template split_accum<E>() && KEYS == 1 && NS == 1;
+  constexpr int ACCS = KEYS * PARTS;  // accumulator a = m * PARTS + q of a sample: key m, key part q
 
-  elem accum[ACCS][E];
+  elem accum[NS][ACCS][E];
   // second accumulator set of fields that add up unreduced (h, l) product pairs (F::split_accum)
   elem accum_lo[SPLIT ? ACCS : 1][SPLIT ? E : 1];
 #pragma unroll
-  for (int q = 0; q < ACCS; ++q)
+  for (int s = 0; s < NS; ++s)
 #pragma unroll
-    for (int r = 0; r < E; ++r) {
-      accum[q][r] = SPLIT ? F::accum_init() : F::zero();
-      if (SPLIT) accum_lo[SPLIT ? q : 0][SPLIT ? r : 0] = F::zero();
-    }
+    for (int q = 0; q < ACCS; ++q)
+#pragma unroll
+      for (int r = 0; r < E; ++r) {
+        accum[s][q][r] = SPLIT ? F::accum_init() : F::zero();
+        if (SPLIT) accum_lo[SPLIT ? q : 0][SPLIT ? r : 0] = F::zero();
+      }
 
-  // v[r]: rounded coefficient; once a limb has been consumed its bit log_base-1 carries the digit
+  // v[s][r]: rounded coefficient; once a limb has been consumed its bit log_base-1 carries the digit
   // chain's carry to the next limb (decompose_limb_fast)
   // The lane-uniform constants of the forward transforms' top window (wave_ntt.h::TopConsts) are fetched
   // while the operand is read and rounded, stay in scalar registers for all levels, and make room for
   // the inverse transforms' block after the last level.
   TopConsts<F, LT, G, true> ftop;
   if constexpr (TFHE_TOP_PREFETCH) ftop.issue(c.twiddles_uniform());
-  u32 v[EC];
+  u32 v[NS][EC];
   const RoundConsts rc = round_consts(P.ignored_bits);
 #pragma unroll
-  for (int r = 0; r < EC; ++r) v[r] = round_value_fast(src(r * T + lane), rc);
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int r = 0; r < EC; ++r) v[s][r] = round_value_fast(src(s, r * T + lane), rc);
   if constexpr (TFHE_TOP_PREFETCH) ftop.ready();
 
   // Key tiles of one level for my column: idx = s * PARTS + q, s = source polynomial 0..K, q = part.
@@ -216,21 +228,27 @@ TFHE_HD void external_product_team_keys(const Ctx& c, const PbsParams& P, const 
 #define TFHE_CHUNK 8
 #endif
   constexpr int TILES = (K + 1) * ACCS;
-  constexpr int CH_MAX = TFHE_CHUNK * 8 / (int)sizeof(elem);  // TFHE_CHUNK counts 8-byte registers
+  // (NS samples share a chunk: half the registers per chunk give the same arithmetic per fetch, and the staging
+  // buffers and the digit-spectrum pieces of NS samples fit beside NS accumulator sets)
+#ifndef TFHE_NS_CHUNK_DIV
+#define TFHE_NS_CHUNK_DIV 2
+#endif
+  constexpr int CH_MAX = TFHE_CHUNK * 8 / (int)sizeof(elem) / (NS > 1 ? TFHE_NS_CHUNK_DIV : 1);  // TFHE_CHUNK counts 8-byte registers
   constexpr int CH = E < CH_MAX ? E : CH_MAX;
   constexpr int CHUNKS = TILES * (E / CH);
-  // tile of source polynomial s and accumulator a = (key m, part q)
-  auto tile_ptr = [&](u32 level, int s, int a) -> const elem* {
+  // tile of source polynomial sp and accumulator a = (key m, part q)
+  auto tile_ptr = [&](u32 level, int sp, int a) -> const elem* {
     const int m = a / PARTS, q = a % PARTS;
-    return ggsw + (size_t)m * ggsw_words + (((size_t)(s * P.levels + level) * (K + 1) + me) * PARTS + q) * N;
+    return ggsw + (size_t)m * ggsw_words + (((size_t)(sp * P.levels + level) * (K + 1) + me) * PARTS + q) * N;
   };
   // Spectrum exchange through LDS.  With ONE buffer per group a level needs two team barriers
-  // (publish -> consume -> the next transform reuses the buffer).  With TWO buffers level t works in
-  // buffer t & 1: whoever still reads buffer (t-1) & 1 is not disturbed, and buffer t & 1 was last
+  // (publish -> consume -> the next transform reuses the buffer).  With TWO buffers (and one sample) level t works
+  // in buffer t & 1: whoever still reads buffer (t-1) & 1 is not disturbed, and buffer t & 1 was last
   // read in the MAC of level t-2, which every wave left before the barrier of level t-1 -- one
   // barrier per level, plus one at the end of the product (the first level of the next product
   // writes buffer 0 again).  The inverse transforms run in buffer levels & 1 under the same rule.
-  const bool two = c.exchange_buffers() == 2;
+  // With NS samples buffer s belongs to sample s and every level has its two barriers -- for NS products.
+  const bool two = NS == 1 && c.exchange_buffers() == 2;
 #ifndef TFHE_KEY_BUFFERS
 #define TFHE_KEY_BUFFERS 2
 #endif
@@ -245,116 +263,169 @@ TFHE_HD void external_product_team_keys(const Ctx& c, const PbsParams& P, const 
 #pragma unroll
     for (int r = 0; r < CH; ++r) kbuf[buf][r] = tile[spectrum_slot<LT, G, (int)sizeof(elem)>(lane, r0 + r)];
   };
+  // the contexts of the samples' buffers (NS == 1: the level's parity buffer, see above)
+  auto buffers_of_level = [&](u32 t, Ctx (&cl)[NS]) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) cl[s] = c.with_exchange_buffer(NS > 1 ? s : (two ? (int)(t & 1u) : 0));
+  };
   // (not unrolled: with the level count fixed at 3 and the loop fully unrolled the kernel issues 2.8 %
   // fewer instructions from 3x the code and runs no faster, profiles/r02_kernel_ab.txt)
 #pragma unroll 1
   for (u32 t = 0; t < P.levels; ++t) {  // limbs LSB -> MSB; level index counts from the MSB
     const u32 level = P.levels - 1 - t;
     const u32 shift = P.first_shift + P.log_base * t;
-    const Ctx cl = c.with_exchange_buffer(two ? (int)(t & 1u) : 0);
+    Ctx cl[NS];
+    buffers_of_level(t, cl);
     static_for<0, (NB - 1 < CHUNKS ? NB - 1 : CHUNKS)>([&](auto pre_c) { load_chunk(level, pre_c, decltype(pre_c)::value); });
     c.compiler_fence();
-    {
-      elem work[E];
-      const u32 carry_width = (t == 0) ? 0u : 1u;  // wave-uniform: the lowest kept limb has no carry-in
+    // The samples' digit rows are transformed one after the other (TFHE_NS_LOCKSTEP_FORWARD = 0): in lockstep
+    // (ntt_forward_multi over all of them, shared transposes) two working arrays are live next to every sample's
+    // accumulators and the kernels of the 168-register shapes spill (89 / 33 registers at N = 2048 / N = 512, k = 2);
+    // the inverse transforms do run in lockstep -- their arrays ARE the accumulators.
+#ifndef TFHE_NS_LOCKSTEP_FORWARD
+#define TFHE_NS_LOCKSTEP_FORWARD 0
+#endif
+    constexpr int FS = (NS > 1 && !TFHE_NS_LOCKSTEP_FORWARD) ? 1 : NS;  // samples per forward transform call
+    const u32 carry_width = (t == 0) ? 0u : 1u;  // wave-uniform: the lowest kept limb has no carry-in
+#pragma unroll
+    for (int s0 = 0; s0 < NS; s0 += FS) {
+      elem work[FS][E];
       // F::kMaxLogBase: the largest gadget base the field's exactness bound admits at all; only the
       // Goldilocks fields reach bases above 2^23 (one-level decompositions) and branch at run time
       if (F::kMaxLogBase <= 23 || P.log_base <= 23) {
 #pragma unroll
-        for (int r = 0; r < E; ++r) {
-          u32 dg[CO];
+        for (int s = 0; s < FS; ++s)
 #pragma unroll
-          for (int q = 0; q < CO; ++q) dg[q] = decompose_limb_fast<true>(v[r + q * E], shift, P.log_base, carry_width);
-          work[r] = F::from_digits(dg);
-        }
+          for (int r = 0; r < E; ++r) {
+            u32 dg[CO];
+#pragma unroll
+            for (int q = 0; q < CO; ++q) dg[q] = decompose_limb_fast<true>(v[s0 + s][r + q * E], shift, P.log_base, carry_width);
+            work[s][r] = F::from_digits(dg);
+          }
       } else {
 #pragma unroll
-        for (int r = 0; r < E; ++r) {
-          u32 dg[CO];
+        for (int s = 0; s < FS; ++s)
 #pragma unroll
-          for (int q = 0; q < CO; ++q) dg[q] = decompose_limb_fast<false>(v[r + q * E], shift, P.log_base, carry_width);
-          work[r] = F::from_digits(dg);
-        }
+          for (int r = 0; r < E; ++r) {
+            u32 dg[CO];
+#pragma unroll
+            for (int q = 0; q < CO; ++q) dg[q] = decompose_limb_fast<false>(v[s0 + s][r + q * E], shift, P.log_base, carry_width);
+            work[s][r] = F::from_digits(dg);
+          }
       }
       // digits are tiny (|d| <= B <= 2^F::kSmallBits, enforced when the context picks the field):
       // the first butterfly stage uses F::mul_small.  A team barrier precedes every level (the
-      // caller's for level 0, the previous level's below) and nobody reads this buffer after it.
-      if constexpr (TFHE_TOP_PREFETCH)
-        ntt_forward<F, LT, G, true, true>(cl, work, ftop);
-      else
-        ntt_forward<F, LT, G, true, true>(cl, work);
-      if (F::kReduceSpectrum) {  // little lazy headroom: MAC terms must start from |d| <= p/2
+      // caller's for level 0, the previous level's below) and nobody reads these buffers after it.
+      Ctx cf[FS];
 #pragma unroll
-        for (int r = 0; r < E; ++r) work[r] = F::reduce(work[r]);
+      for (int s = 0; s < FS; ++s) cf[s] = cl[s0 + s];
+      if constexpr (TFHE_TOP_PREFETCH) {
+        ntt_forward_multi<F, LT, G, true, true>(cf, work, ftop);
+      } else {
+        const TopFromTable<elem> top{c.twiddles_uniform(), 1 << LT};
+        ntt_forward_multi<F, LT, G, true, true>(cf, work, top);
       }
-      // publish: element r of thread tid at exchange_slot(tid, r) -- inside my wave's own part of
-      // the buffer (wave_ntt.h), conflict-free 8-byte accesses
-      elem* mine = cl.scratch();
 #pragma unroll
-      for (int r = 0; r < E; ++r) mine[exchange_slot<LT, G>(lane, r)] = work[r];
+      for (int s = 0; s < FS; ++s) {
+        if (F::kReduceSpectrum) {  // little lazy headroom: MAC terms must start from |d| <= p/2
+#pragma unroll
+          for (int r = 0; r < E; ++r) work[s][r] = F::reduce(work[s][r]);
+        }
+        // publish: element r of thread tid at exchange_slot(tid, r) -- inside my wave's own part of
+        // the buffer (wave_ntt.h), conflict-free 8-byte accesses
+        elem* mine = cf[s].scratch();
+#pragma unroll
+        for (int r = 0; r < E; ++r) mine[exchange_slot<LT, G>(lane, r)] = work[s][r];
+      }
     }
     c.team_sync();
-    // chunk order: source polynomial s, then the CH-register piece of its spectrum, then the
-    // accumulator (key, key part) -- so that a piece of the digit spectrum is read from LDS once and
-    // used for every key and part
-    elem d[CH];
+    // chunk order: source polynomial sp, then the CH-register piece of its spectrum, then the
+    // accumulator (key, key part) -- so that a piece of a digit spectrum is read from LDS once and
+    // used for every key and part, and a key chunk is fetched once and used for every sample
+    elem d[NS][CH];
     static_for<0, CHUNKS>([&](auto ci_c) {
       constexpr int ci = decltype(ci_c)::value;
       constexpr int PIECES = E / CH;
-      constexpr int q = ci % ACCS, r0 = ((ci / ACCS) % PIECES) * CH, s = ci / (ACCS * PIECES);
+      constexpr int q = ci % ACCS, r0 = ((ci / ACCS) % PIECES) * CH, sp = ci / (ACCS * PIECES);
       constexpr int cur = ci % NB;
       if constexpr (ci + NB - 1 < CHUNKS) load_chunk(level, IntC<ci + NB - 1>{}, (ci + NB - 1) % NB);
       if constexpr (q == 0) {
-        const elem* spec = cl.scratch_of(s);
 #pragma unroll
-        for (int r = 0; r < CH; ++r) d[r] = spec[exchange_slot<LT, G>(lane, r0 + r)];
+        for (int s = 0; s < NS; ++s) {
+          const elem* spec = cl[s].scratch_of(sp);
+#pragma unroll
+          for (int r = 0; r < CH; ++r) d[s][r] = spec[exchange_slot<LT, G>(lane, r0 + r)];
+        }
       }
       c.compiler_fence();  // keep the next chunk's loads above this chunk's arithmetic
 #pragma unroll
-      for (int r = 0; r < CH; ++r) {
-        if (SPLIT)
-          F::mac(d[r], kbuf[cur][r], accum[q][r0 + r], accum_lo[SPLIT ? q : 0][SPLIT ? r0 + r : 0]);
-        else
-          accum[q][r0 + r] = F::mul_add(d[r], kbuf[cur][r], accum[q][r0 + r]);
-      }
+      for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int r = 0; r < CH; ++r) {
+          if (SPLIT)
+            F::mac(d[s][r], kbuf[cur][r], accum[s][q][r0 + r], accum_lo[SPLIT ? q : 0][SPLIT ? r0 + r : 0]);
+          else
+            accum[s][q][r0 + r] = F::mul_add(d[s][r], kbuf[cur][r], accum[s][q][r0 + r]);
+        }
     });
     if (!two) c.team_sync();  // everyone is done reading before the next transform reuses the buffer
   }
 
-  const Ctx ci = c.with_exchange_buffer(two ? (int)(P.levels & 1u) : 0);
+  Ctx ci[NS];
+  buffers_of_level(P.levels, ci);
   TopConsts<F, LT, G, false> itop;  // arrives during the first two passes of the first inverse transform
   if constexpr (TFHE_TOP_PREFETCH) itop.issue(c.twiddles_uniform());
   static_for<0, KEYS>([&](auto key_c) {
     constexpr int m = decltype(key_c)::value;
     static_for<0, PARTS>([&](auto part_c) {
       constexpr int q = m * PARTS + decltype(part_c)::value;
+      // part q of every sample goes through the inverse transform together
+      elem x[NS][E];
 #pragma unroll
-      for (int r = 0; r < E; ++r)
-        accum[q][r] = SPLIT ? F::mac_finish(accum[q][r], accum_lo[SPLIT ? q : 0][SPLIT ? r : 0])
-                            : F::before_inverse(accum[q][r]);
+      for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int r = 0; r < E; ++r)
+          x[s][r] = SPLIT ? F::mac_finish(accum[s][q][r], accum_lo[SPLIT ? q : 0][SPLIT ? r : 0])
+                          : F::before_inverse(accum[s][q][r]);
       if constexpr (TFHE_TOP_PREFETCH) {
         if constexpr (q == 0) itop.ready();  // nothing else is in flight here: the wait is for the block alone
-        ntt_inverse<F, LT, G>(ci, accum[q], itop);
+        ntt_inverse_multi<F, LT, G>(ci, x, itop);
+      } else {
+        const TopFromTable<elem> top{c.twiddles_uniform(), 1 << LT};
+        ntt_inverse_multi<F, LT, G>(ci, x, top);
       }
-      else
-        ntt_inverse<F, LT, G>(ci, accum[q]);
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int r = 0; r < E; ++r) accum[s][q][r] = x[s][r];
     });
 #pragma unroll
-    for (int r = 0; r < E; ++r) {
-      elem parts[PARTS];
+    for (int s = 0; s < NS; ++s)
 #pragma unroll
-      for (int q = 0; q < PARTS; ++q) parts[q] = accum[m * PARTS + q][r];
-      u32 vals[CO];
-      F::finish(parts, vals);
+      for (int r = 0; r < E; ++r) {
+        elem parts[PARTS];
 #pragma unroll
-      for (int q = 0; q < CO; ++q) out(m, (r + q * E) * T + lane, vals[q]);
-    }
+        for (int q = 0; q < PARTS; ++q) parts[q] = accum[s][m * PARTS + q][r];
+        u32 vals[CO];
+        F::finish(parts, vals);
+#pragma unroll
+        for (int q = 0; q < CO; ++q) out(m, s, (r + q * E) * T + lane, vals[q]);
+      }
     end_of_key(m);
   });
   // two buffers: the MAC reads of the last level must be over before a following product (or any
   // other user of the buffers) writes buffer 0; this barrier also orders the out() stores of the
   // whole team.  One buffer: the last level already ended with a barrier.
   if (two) c.team_sync();
+}
+
+// one operand, KEYS keys (the unrolled blind rotation): src(j), out(m, j, value)
+template <class F, int LOGN, int K, int G, int KEYS, class Ctx, class Src, class Out, class EndKey>
+TFHE_HD void external_product_team_keys(const Ctx& c, const PbsParams& P, const typename F::elem* ggsw,
+                                        size_t ggsw_words, Src src, Out out, EndKey end_of_key) {
+  external_product_team_multi<F, LOGN, K, G, KEYS, 1>(
+      c, P, ggsw, ggsw_words, [&](int, int j) -> u32 { return src(j); },
+      [&](int m, int, int j, u32 value) { out(m, j, value); }, end_of_key);
 }
 
 // one GGSW (ggsw.rs:132-161)
@@ -366,24 +437,27 @@ TFHE_HD void external_product_team(const Ctx& c, const PbsParams& P, const typen
 }
 
 // ---------------------------------------------------------------------------------------------
-// Blind rotation of ONE LWE sample (bootstrapping.rs:67-105) by a team of K+1 groups of G waves.
-// Group c keeps polynomial c of the accumulator in its LDS array c.acc() (N u32, natural order)
-// for all n iterations; on return it holds polynomial c of the final GLWE accumulator.
+// Blind rotation of NS LWE samples (bootstrapping.rs:67-105 for each) by a team of K+1 groups of G waves.
+// Group c keeps polynomial c of sample s's accumulator in its LDS array c.acc(s) (N u32, natural order)
+// for all n iterations; on return it holds polynomial c of the final GLWE accumulator of sample s.
+// NS = 1 is the plain one-sample-per-team form; with NS = 2 every CMUX iteration multiplies both samples'
+// rotated differences with GGSW_i in one pass (external_product_team_multi).
 // ---------------------------------------------------------------------------------------------
-template <class F, int LOGN, int K, int G, class Ctx>
-TFHE_HD void blind_rotate_team(const Ctx& c, const PbsParams& P, const u32* lwe /* n+1 */,
-                               const u32* tv /* N, un-encoded */,
-                               const typename F::elem* bsk /* prepared */) {
+template <class F, int LOGN, int K, int G, int NS, class Ctx>
+TFHE_HD void blind_rotate_team_multi(const Ctx& c, const PbsParams& P, const u32* const* lwe /* NS x (n+1) */,
+                                     const u32* const* tv /* NS x N, un-encoded */,
+                                     const typename F::elem* bsk /* prepared */) {
   constexpr int E = NttShape<LOGN, G>::kE;
   constexpr int T = NttShape<LOGN, G>::kThreads;
   constexpr int N = 1 << LOGN;
   const int lane = c.tid();
   const int me = c.group();
-  u32* acc = c.acc();
 
   // acc = X^{-b~} * (0, ..., 0, tv << tv_shift): only the body polynomial (wave K) is non-zero
-  {
-    const u32 b_tilde = switch_modulus_2n(lwe[P.n], LOGN);
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    u32* acc = c.acc(s);
+    const u32 b_tilde = switch_modulus_2n(lwe[s][P.n], LOGN);
     const u32 m = (2u * N - b_tilde) & (2u * N - 1u);
     const int deg = (int)(m & (N - 1));
     const u32 flip = (m >> LOGN) & 1u;
@@ -392,29 +466,43 @@ TFHE_HD void blind_rotate_team(const Ctx& c, const PbsParams& P, const u32* lwe 
       const int j = r * T + lane;
       u32 val = 0;
       if (me == K) {
-        const u32 t = tv[(j - deg) & (N - 1)] << P.tv_shift;
+        const u32 t = tv[s][(j - deg) & (N - 1)] << P.tv_shift;
         val = (flip ^ (u32)(j < deg)) ? (0u - t) : t;
       }
       acc[j] = val;
     }
-    c.poly_sync();
   }
+  c.poly_sync();
 
   const size_t ggsw_words = (size_t)(K + 1) * P.levels * (K + 1) * F::kParts * (N >> F::kLogShrink);  // elements
 #pragma unroll 1
   for (u32 i = 0; i < P.n; ++i) {
-    const u32 a_tilde = c.uniform(switch_modulus_2n(lwe[i], LOGN));
+    u32 a_tilde[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) a_tilde[s] = c.uniform(switch_modulus_2n(lwe[s][i], LOGN));
     // cmux(ggsw_i, acc, X^{a~} * acc) = external_product(ggsw_i, X^{a~} acc - acc) + acc.
     // (a~ = 0 gives all-zero digits and leaves acc unchanged; it is not skipped because every wave
     // of the team has to take part in the barriers.)
-    auto src = [&](int j) -> u32 { return monomial_coeff<LOGN>(acc, j, a_tilde) - acc[j]; };
+    auto src = [&](int s, int j) -> u32 {
+      const u32* acc = c.acc(s);
+      return monomial_coeff<LOGN>(acc, j, a_tilde[s]) - acc[j];
+    };
     // all rotated reads of acc happen before the first inverse transform: in-place update is safe
-    auto out = [&](int j, u32 value) { acc[j] += value; };
-    external_product_team<F, LOGN, K, G>(c, P, bsk + (size_t)i * ggsw_words, src, out);
-    // G > 1: the other waves of my group read what I just wrote (with two exchange buffers the
+    auto out = [&](int, int s, int j, u32 value) { c.acc(s)[j] += value; };
+    external_product_team_multi<F, LOGN, K, G, 1, NS>(c, P, bsk + (size_t)i * ggsw_words, 0, src, out, [](int) {});
+    // G > 1: the other waves of my group read what I just wrote (with two exchange buffers and one sample the
     // product already ended with a team barrier)
-    if (c.exchange_buffers() != 2) c.poly_sync();
+    if (NS > 1 || c.exchange_buffers() != 2) c.poly_sync();
   }
+}
+
+template <class F, int LOGN, int K, int G, class Ctx>
+TFHE_HD void blind_rotate_team(const Ctx& c, const PbsParams& P, const u32* lwe /* n+1 */,
+                               const u32* tv /* N, un-encoded */,
+                               const typename F::elem* bsk /* prepared */) {
+  const u32* const lwes[1] = {lwe};
+  const u32* const tvs[1] = {tv};
+  blind_rotate_team_multi<F, LOGN, K, G, 1>(c, P, lwes, tvs, bsk);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -441,7 +529,7 @@ TFHE_HD void blind_rotate_bmmp_team(const Ctx& c, const PbsParams& P, const u32*
   constexpr int N = 1 << LOGN;
   const int lane = c.tid();
   const int me = c.group();
-  u32* acc = c.acc();
+  u32* acc = c.acc(0);
   {
     const u32 b_tilde = switch_modulus_2n(lwe[P.n], LOGN);
     const u32 m = (2u * N - b_tilde) & (2u * N - 1u);
@@ -486,13 +574,13 @@ TFHE_HD void blind_rotate_bmmp_team(const Ctx& c, const PbsParams& P, const u32*
 // sample_extract at index 0 (bootstrapping.rs:122-156): wave c < K writes the N mask words of its
 // polynomial, wave K writes the body word
 template <int LOGN, int K, int G, class Ctx>
-TFHE_HD void sample_extract_team(const Ctx& c, u32* out /* K*N + 1 */) {
+TFHE_HD void sample_extract_team(const Ctx& c, u32* out /* K*N + 1 */, int s = 0) {
   constexpr int E = NttShape<LOGN, G>::kE;
   constexpr int T = NttShape<LOGN, G>::kThreads;
   constexpr int N = 1 << LOGN;
   const int lane = c.tid();
   const int me = c.group();
-  const u32* acc = c.acc();
+  const u32* acc = c.acc(s);
   if (me < K) {
 #pragma unroll
     for (int r = 0; r < E; ++r) {

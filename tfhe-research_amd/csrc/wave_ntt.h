@@ -127,9 +127,9 @@ TFHE_HD int ntt_twiddle_slot(int idx) {
 // (eight loads in flight per thread: one load, wait, store per trip made the copy a chain of nine global
 // round trips at the start of every team -- several microseconds, which the persistent external-product
 // kernel pays once per four products at batch 4096)
-template <int LOGN, int G, class Elem>
+// (W: entries to copy -- the whole table, or only psi_rev[0 .. N) for a field without fused-stage constants)
+template <int LOGN, int G, class Elem, int W = ntt_twiddle_words(1 << LOGN)>
 TFHE_HD void ntt_stage_twiddles(Elem* dst, const Elem* src, int tid, int nthreads) {
-  constexpr int W = ntt_twiddle_words(1 << LOGN);
   constexpr int U = 8;
   for (int base = tid; base < W; base += U * nthreads) {
     Elem tmp[U];
@@ -365,21 +365,38 @@ TFHE_HD int exchange_slot(int tid, int r) {
 // SKIP_LEAD: the caller guarantees that a workgroup barrier already separates every earlier read of
 // the buffer from this call (no read of it since), so the leading barrier of a cross-writing
 // transpose is dropped.
-template <class F, int LOGN, int G, int LO_FROM, int LO_TO, bool SKIP_LEAD = false, class Ctx>
-TFHE_HD void ntt_transpose(const Ctx& c, typename F::elem (&x)[NttShape<LOGN, G>::kE]) {
+// NS polynomials at once (ntt_transpose_multi): polynomial s goes through the buffer of context c[s]; the
+// contexts differ only in the buffer they select, and the waits and barriers are shared -- all stores, one
+// synchronisation, all loads -- so two polynomials cost one set of barriers (and one LDS round trip of latency).
+template <class F, int LOGN, int G, int LO_FROM, int LO_TO, bool SKIP_LEAD = false, int NS, class Ctx>
+TFHE_HD void ntt_transpose_multi(const Ctx (&c)[NS], typename F::elem (&x)[NS][NttShape<LOGN, G>::kE]) {
   constexpr int E = NttShape<LOGN, G>::kE;
   constexpr bool WRITES_CROSS = G > 1 && LO_FROM > 6;
   constexpr bool READS_CROSS = G > 1 && LO_TO > 6;
   static_assert(!(WRITES_CROSS && READS_CROSS), "one of the two windows is a low one");
-  typename F::elem* buf = c.scratch();
-  const int tid = c.tid();
-  if (WRITES_CROSS && !SKIP_LEAD) c.poly_sync();
+  const int tid = c[0].tid();
+  if (WRITES_CROSS && !SKIP_LEAD) c[0].poly_sync();
 #pragma unroll
-  for (int r = 0; r < E; ++r) buf[ntt_swizzle<LOGN, G>(ntt_index<LOGN, G, LO_FROM>(tid, r))] = x[r];
-  if (WRITES_CROSS || READS_CROSS) c.poly_sync(); else c.wave_sync();
+  for (int s = 0; s < NS; ++s) {
+    typename F::elem* buf = c[s].scratch();
 #pragma unroll
-  for (int r = 0; r < E; ++r) x[r] = buf[ntt_swizzle<LOGN, G>(ntt_index<LOGN, G, LO_TO>(tid, r))];
-  if (READS_CROSS) c.poly_sync(); else c.wave_sync();
+    for (int r = 0; r < E; ++r) buf[ntt_swizzle<LOGN, G>(ntt_index<LOGN, G, LO_FROM>(tid, r))] = x[s][r];
+  }
+  if (WRITES_CROSS || READS_CROSS) c[0].poly_sync(); else c[0].wave_sync();
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const typename F::elem* buf = c[s].scratch();
+#pragma unroll
+    for (int r = 0; r < E; ++r) x[s][r] = buf[ntt_swizzle<LOGN, G>(ntt_index<LOGN, G, LO_TO>(tid, r))];
+  }
+  if (READS_CROSS) c[0].poly_sync(); else c[0].wave_sync();
+}
+
+template <class F, int LOGN, int G, int LO_FROM, int LO_TO, bool SKIP_LEAD = false, class Ctx>
+TFHE_HD void ntt_transpose(const Ctx& c, typename F::elem (&x)[NttShape<LOGN, G>::kE]) {
+  const Ctx cs[1] = {c};
+  ntt_transpose_multi<F, LOGN, G, LO_FROM, LO_TO, SKIP_LEAD, 1>(
+      cs, reinterpret_cast<typename F::elem (&)[1][NttShape<LOGN, G>::kE]>(x));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -449,7 +466,7 @@ struct NoPassTwiddles {};
 template <class F, int LOGN, int G, int LO, int BHI, int BLO, bool SMALL_FIRST, class Ctx, class Top, class Pre = NoPassTwiddles>
 TFHE_HD void ntt_pass_forward(const Ctx& c, typename F::elem (&x)[NttShape<LOGN, G>::kE], const Top& top,
                               const Pre& pre = Pre{}) {
-  constexpr bool PRE = !std::is_same<Pre, NoPassTwiddles>::value;
+  constexpr bool PRE = !std::is_base_of<NoPassTwiddles, Pre>::value;
   typedef typename F::elem elem;
   constexpr int E = NttShape<LOGN, G>::kE;
   constexpr int e = NttShape<LOGN, G>::kEBits;
@@ -525,7 +542,7 @@ TFHE_HD void ntt_pass_forward(const Ctx& c, typename F::elem (&x)[NttShape<LOGN,
 template <class F, int LOGN, int G, int LO, int BHI, int BLO, class Ctx, class Top, class Pre = NoPassTwiddles>
 TFHE_HD void ntt_pass_inverse(const Ctx& c, typename F::elem (&x)[NttShape<LOGN, G>::kE], const Top& top,
                               const Pre& pre = Pre{}) {
-  constexpr bool PRE = !std::is_same<Pre, NoPassTwiddles>::value;
+  constexpr bool PRE = !std::is_base_of<NoPassTwiddles, Pre>::value;
   typedef typename F::elem elem;
   constexpr int E = NttShape<LOGN, G>::kE;
   constexpr int e = NttShape<LOGN, G>::kEBits;
@@ -578,46 +595,64 @@ TFHE_HD void ntt_pass_inverse(const Ctx& c, typename F::elem (&x)[NttShape<LOGN,
 // AFTER_BARRIER: nobody has read the buffer since the last workgroup barrier (see ntt_transpose).
 // top: where the top window's lane-uniform constants come from (TopFromTable, or a TopConsts the
 // caller has issued earlier and on which ready() has been called).
+// ntt_forward_multi / ntt_inverse_multi transform NS polynomials in step (polynomial s through the buffer of c[s]):
+// every register pass is run for each of them in turn, the transposes are shared (ntt_transpose_multi), and a low
+// window's twiddles are fetched once for all of them.
+template <class F, int LOGN, int G, int LO, int BHI, int BLO, bool SMALL, int NS, class Ctx, class Top, class Pre>
+TFHE_HD void ntt_pass_forward_each(const Ctx (&c)[NS], typename F::elem (&x)[NS][NttShape<LOGN, G>::kE], const Top& top,
+                                   const Pre& pre) {
+#pragma unroll
+  for (int s = 0; s < NS; ++s) ntt_pass_forward<F, LOGN, G, LO, BHI, BLO, SMALL>(c[s], x[s], top, pre);
+}
+template <class F, int LOGN, int G, int LO, int BHI, int BLO, int NS, class Ctx, class Top, class Pre>
+TFHE_HD void ntt_pass_inverse_each(const Ctx (&c)[NS], typename F::elem (&x)[NS][NttShape<LOGN, G>::kE], const Top& top,
+                                   const Pre& pre) {
+#pragma unroll
+  for (int s = 0; s < NS; ++s) ntt_pass_inverse<F, LOGN, G, LO, BHI, BLO>(c[s], x[s], top, pre);
+}
+
+// the twiddles of a low pass: fetched ahead (PassTwiddles) by the fields that opt in, otherwise read by the pass itself
+template <class F, int LOGN, int G, int LO, int BHI, int BLO, bool INVERSE, bool PRE>
+struct LowPassTwiddles : PassTwiddles<F, LOGN, G, LO, BHI, BLO, INVERSE> {};
+template <class F, int LOGN, int G, int LO, int BHI, int BLO, bool INVERSE>
+struct LowPassTwiddles<F, LOGN, G, LO, BHI, BLO, INVERSE, false> : NoPassTwiddles {
+  template <class Ctx>
+  TFHE_HD void load(const Ctx&) {}
+};
+
+template <class F, int LOGN, int G, bool SMALL_INPUT = false, bool AFTER_BARRIER = false, int NS, class Ctx, class Top>
+TFHE_HD void ntt_forward_multi(const Ctx (&c)[NS], typename F::elem (&x)[NS][NttShape<LOGN, G>::kE], const Top& top) {
+  using S = NttShape<LOGN, G>;
+  constexpr bool PRE = PreloadsTwiddles<F>::value;
+  ntt_pass_forward_each<F, LOGN, G, S::kLo1, LOGN - 1, S::kTBits, SMALL_INPUT>(c, x, top, NoPassTwiddles{});
+  // every low pass's twiddles are read before the transpose in front of it (PassTwiddles)
+  LowPassTwiddles<F, LOGN, G, S::kLo2, S::kTBits - 1, S::kLo2, false, PRE> t2;
+  t2.load(c[0]);
+  ntt_transpose_multi<F, LOGN, G, S::kLo1, S::kLo2, AFTER_BARRIER>(c, x);
+  ntt_pass_forward_each<F, LOGN, G, S::kLo2, S::kTBits - 1, S::kLo2, false>(c, x, top, t2);
+  LowPassTwiddles<F, LOGN, G, S::kLo3, S::kLo2 - 1, S::kLo3, false, PRE> t3;
+  t3.load(c[0]);
+  ntt_transpose_multi<F, LOGN, G, S::kLo2, S::kLo3>(c, x);
+  ntt_pass_forward_each<F, LOGN, G, S::kLo3, S::kLo2 - 1, S::kLo3, false>(c, x, top, t3);
+  if constexpr (S::kPasses >= 4) {
+    LowPassTwiddles<F, LOGN, G, S::kLo4, S::kLo3 - 1, S::kLo4, false, PRE> t4;
+    t4.load(c[0]);
+    ntt_transpose_multi<F, LOGN, G, S::kLo3, S::kLo4>(c, x);
+    ntt_pass_forward_each<F, LOGN, G, S::kLo4, S::kLo3 - 1, S::kLo4, false>(c, x, top, t4);
+  }
+  if constexpr (S::kPasses == 5) {
+    LowPassTwiddles<F, LOGN, G, S::kLo5, S::kLo4 - 1, 0, false, PRE> t5;
+    t5.load(c[0]);
+    ntt_transpose_multi<F, LOGN, G, S::kLo4, S::kLo5>(c, x);
+    ntt_pass_forward_each<F, LOGN, G, S::kLo5, S::kLo4 - 1, 0, false>(c, x, top, t5);
+  }
+}
+
 template <class F, int LOGN, int G, bool SMALL_INPUT = false, bool AFTER_BARRIER = false, class Ctx, class Top>
 TFHE_HD void ntt_forward(const Ctx& c, typename F::elem (&x)[NttShape<LOGN, G>::kE], const Top& top) {
-  using S = NttShape<LOGN, G>;
-  ntt_pass_forward<F, LOGN, G, S::kLo1, LOGN - 1, S::kTBits, SMALL_INPUT>(c, x, top);
-  if constexpr (PreloadsTwiddles<F>::value) {
-    // every low pass's twiddles are read before the transpose in front of it (PassTwiddles)
-    PassTwiddles<F, LOGN, G, S::kLo2, S::kTBits - 1, S::kLo2, false> t2;
-    t2.load(c);
-    ntt_transpose<F, LOGN, G, S::kLo1, S::kLo2, AFTER_BARRIER>(c, x);
-    ntt_pass_forward<F, LOGN, G, S::kLo2, S::kTBits - 1, S::kLo2, false>(c, x, top, t2);
-    PassTwiddles<F, LOGN, G, S::kLo3, S::kLo2 - 1, S::kLo3, false> t3;
-    t3.load(c);
-    ntt_transpose<F, LOGN, G, S::kLo2, S::kLo3>(c, x);
-    ntt_pass_forward<F, LOGN, G, S::kLo3, S::kLo2 - 1, S::kLo3, false>(c, x, top, t3);
-    if constexpr (S::kPasses >= 4) {
-      PassTwiddles<F, LOGN, G, S::kLo4, S::kLo3 - 1, S::kLo4, false> t4;
-      t4.load(c);
-      ntt_transpose<F, LOGN, G, S::kLo3, S::kLo4>(c, x);
-      ntt_pass_forward<F, LOGN, G, S::kLo4, S::kLo3 - 1, S::kLo4, false>(c, x, top, t4);
-    }
-    if constexpr (S::kPasses == 5) {
-      PassTwiddles<F, LOGN, G, S::kLo5, S::kLo4 - 1, 0, false> t5;
-      t5.load(c);
-      ntt_transpose<F, LOGN, G, S::kLo4, S::kLo5>(c, x);
-      ntt_pass_forward<F, LOGN, G, S::kLo5, S::kLo4 - 1, 0, false>(c, x, top, t5);
-    }
-  } else {
-    ntt_transpose<F, LOGN, G, S::kLo1, S::kLo2, AFTER_BARRIER>(c, x);
-    ntt_pass_forward<F, LOGN, G, S::kLo2, S::kTBits - 1, S::kLo2, false>(c, x, top);
-    ntt_transpose<F, LOGN, G, S::kLo2, S::kLo3>(c, x);
-    ntt_pass_forward<F, LOGN, G, S::kLo3, S::kLo2 - 1, S::kLo3, false>(c, x, top);
-    if constexpr (S::kPasses >= 4) {
-      ntt_transpose<F, LOGN, G, S::kLo3, S::kLo4>(c, x);
-      ntt_pass_forward<F, LOGN, G, S::kLo4, S::kLo3 - 1, S::kLo4, false>(c, x, top);
-    }
-    if constexpr (S::kPasses == 5) {
-      ntt_transpose<F, LOGN, G, S::kLo4, S::kLo5>(c, x);
-      ntt_pass_forward<F, LOGN, G, S::kLo5, S::kLo4 - 1, 0, false>(c, x, top);
-    }
-  }
+  const Ctx cs[1] = {c};
+  ntt_forward_multi<F, LOGN, G, SMALL_INPUT, AFTER_BARRIER, 1>(
+      cs, reinterpret_cast<typename F::elem (&)[1][NttShape<LOGN, G>::kE]>(x), top);
 }
 
 template <class F, int LOGN, int G, bool SMALL_INPUT = false, bool AFTER_BARRIER = false, class Ctx>
@@ -628,48 +663,39 @@ TFHE_HD void ntt_forward(const Ctx& c, typename F::elem (&x)[NttShape<LOGN, G>::
 
 // in: x[r] = A_bitrev[tid*E + r].  out: x[r] = N * a[r*64G + tid] (unscaled inverse).
 // A prefetched `top` must be ready() before the call.
+// (the first pass's twiddles are read on entry -- nothing to hide them behind but the caller's last
+// instructions --, every later low pass's before the transpose in front of it)
+template <class F, int LOGN, int G, int NS, class Ctx, class Top>
+TFHE_HD void ntt_inverse_multi(const Ctx (&c)[NS], typename F::elem (&x)[NS][NttShape<LOGN, G>::kE], const Top& top) {
+  using S = NttShape<LOGN, G>;
+  constexpr bool PRE = PreloadsTwiddles<F>::value;
+  if constexpr (S::kPasses == 5) {
+    LowPassTwiddles<F, LOGN, G, S::kLo5, S::kLo4 - 1, 0, true, PRE> t5;
+    t5.load(c[0]);
+    ntt_pass_inverse_each<F, LOGN, G, S::kLo5, S::kLo4 - 1, 0>(c, x, top, t5);
+  }
+  if constexpr (S::kPasses >= 4) {
+    LowPassTwiddles<F, LOGN, G, S::kLo4, S::kLo3 - 1, S::kLo4, true, PRE> t4;
+    t4.load(c[0]);
+    if constexpr (S::kPasses == 5) ntt_transpose_multi<F, LOGN, G, S::kLo5, S::kLo4>(c, x);
+    ntt_pass_inverse_each<F, LOGN, G, S::kLo4, S::kLo3 - 1, S::kLo4>(c, x, top, t4);
+  }
+  LowPassTwiddles<F, LOGN, G, S::kLo3, S::kLo2 - 1, S::kLo3, true, PRE> t3;
+  t3.load(c[0]);
+  if constexpr (S::kPasses >= 4) ntt_transpose_multi<F, LOGN, G, S::kLo4, S::kLo3>(c, x);
+  ntt_pass_inverse_each<F, LOGN, G, S::kLo3, S::kLo2 - 1, S::kLo3>(c, x, top, t3);
+  LowPassTwiddles<F, LOGN, G, S::kLo2, S::kTBits - 1, S::kLo2, true, PRE> t2;
+  t2.load(c[0]);
+  ntt_transpose_multi<F, LOGN, G, S::kLo3, S::kLo2>(c, x);
+  ntt_pass_inverse_each<F, LOGN, G, S::kLo2, S::kTBits - 1, S::kLo2>(c, x, top, t2);
+  ntt_transpose_multi<F, LOGN, G, S::kLo2, S::kLo1>(c, x);
+  ntt_pass_inverse_each<F, LOGN, G, S::kLo1, LOGN - 1, S::kTBits>(c, x, top, NoPassTwiddles{});
+}
+
 template <class F, int LOGN, int G, class Ctx, class Top>
 TFHE_HD void ntt_inverse(const Ctx& c, typename F::elem (&x)[NttShape<LOGN, G>::kE], const Top& top) {
-  using S = NttShape<LOGN, G>;
-  if constexpr (PreloadsTwiddles<F>::value) {
-    // the first pass's twiddles are read on entry (nothing to hide them behind but the caller's last instructions),
-    // every later low pass's before the transpose in front of it
-    if constexpr (S::kPasses == 5) {
-      PassTwiddles<F, LOGN, G, S::kLo5, S::kLo4 - 1, 0, true> t5;
-      t5.load(c);
-      ntt_pass_inverse<F, LOGN, G, S::kLo5, S::kLo4 - 1, 0>(c, x, top, t5);
-    }
-    if constexpr (S::kPasses >= 4) {
-      PassTwiddles<F, LOGN, G, S::kLo4, S::kLo3 - 1, S::kLo4, true> t4;
-      t4.load(c);
-      if constexpr (S::kPasses == 5) ntt_transpose<F, LOGN, G, S::kLo5, S::kLo4>(c, x);
-      ntt_pass_inverse<F, LOGN, G, S::kLo4, S::kLo3 - 1, S::kLo4>(c, x, top, t4);
-    }
-    PassTwiddles<F, LOGN, G, S::kLo3, S::kLo2 - 1, S::kLo3, true> t3;
-    t3.load(c);
-    if constexpr (S::kPasses >= 4) ntt_transpose<F, LOGN, G, S::kLo4, S::kLo3>(c, x);
-    ntt_pass_inverse<F, LOGN, G, S::kLo3, S::kLo2 - 1, S::kLo3>(c, x, top, t3);
-    PassTwiddles<F, LOGN, G, S::kLo2, S::kTBits - 1, S::kLo2, true> t2;
-    t2.load(c);
-    ntt_transpose<F, LOGN, G, S::kLo3, S::kLo2>(c, x);
-    ntt_pass_inverse<F, LOGN, G, S::kLo2, S::kTBits - 1, S::kLo2>(c, x, top, t2);
-    ntt_transpose<F, LOGN, G, S::kLo2, S::kLo1>(c, x);
-    ntt_pass_inverse<F, LOGN, G, S::kLo1, LOGN - 1, S::kTBits>(c, x, top);
-  } else {
-    if constexpr (S::kPasses == 5) {
-      ntt_pass_inverse<F, LOGN, G, S::kLo5, S::kLo4 - 1, 0>(c, x, top);
-      ntt_transpose<F, LOGN, G, S::kLo5, S::kLo4>(c, x);
-    }
-    if constexpr (S::kPasses >= 4) {
-      ntt_pass_inverse<F, LOGN, G, S::kLo4, S::kLo3 - 1, S::kLo4>(c, x, top);
-      ntt_transpose<F, LOGN, G, S::kLo4, S::kLo3>(c, x);
-    }
-    ntt_pass_inverse<F, LOGN, G, S::kLo3, S::kLo2 - 1, S::kLo3>(c, x, top);
-    ntt_transpose<F, LOGN, G, S::kLo3, S::kLo2>(c, x);
-    ntt_pass_inverse<F, LOGN, G, S::kLo2, S::kTBits - 1, S::kLo2>(c, x, top);
-    ntt_transpose<F, LOGN, G, S::kLo2, S::kLo1>(c, x);
-    ntt_pass_inverse<F, LOGN, G, S::kLo1, LOGN - 1, S::kTBits>(c, x, top);
-  }
+  const Ctx cs[1] = {c};
+  ntt_inverse_multi<F, LOGN, G, 1>(cs, reinterpret_cast<typename F::elem (&)[1][NttShape<LOGN, G>::kE]>(x), top);
 }
 
 template <class F, int LOGN, int G, class Ctx>
