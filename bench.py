@@ -607,7 +607,10 @@ def main():
         # replaced as the default (same ciphertexts and key-switching key, a fresh random bootstrapping key: the time does
         # not depend on the data), so that both arithmetic routes are in one record
         try:
-            ctx2 = pkg.Context(params, device=local_rank, backend=pkg.BACKEND_FP64)
+            try:  # the fastest exact prime field that lifts this parameter set: 49-bit (one spectrum), else 42-bit
+                ctx2 = pkg.Context(params, device=local_rank, backend=pkg.BACKEND_FP64_P49)
+            except pkg.TfheError:
+                ctx2 = pkg.Context(params, device=local_rank, backend=pkg.BACKEND_FP64)
             ctx2.use_torch_stream()
             ctx2.load_bootstrapping_key(rand_words(*params.bsk_shape()), ksk)
             ctx2.reserve(batch)
@@ -623,7 +626,8 @@ def main():
             result["exact_ntt_backend"] = {
                 "backend": ctx2.backend, "value": batch * 3 / dt2, "unit": "PBS/s", "steps": 3,
                 "kernel_ms": float(np.mean([ctx2.kernel_ms_ago(i)[0] for i in range(3)])),
-                "what": "the same step with TFHE_BACKEND_FP64 (42-bit prime field, exact integer NTT); not the headline value"}
+                "what": "the same step in the fastest exact prime-field NTT that lifts this parameter set (49-bit, else 42-bit: "
+                        "exact integer arithmetic); not the headline value"}
             ctx2.close()
         except Exception as e:  # noqa: BLE001 - a secondary figure must not lose the benchmark line
             result["exact_ntt_backend"] = {"error": str(e)}

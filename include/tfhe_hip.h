@@ -84,8 +84,9 @@ int tfhe_params_validate(const tfhe_params *params);
  *   GOLDILOCKS p = 2^64 - 2^32 + 1, u64 arithmetic; needs (k+1)*l * N * B * 2^32 < 2^62
  *   GOLDILOCKS_SPLIT  the same field with the key split into 16-bit halves; needs
  *              (k+1)*l * N * B * 2^15 < 2^62, which every base the reference can express satisfies
- *   AUTO       the first of FP64_FFT (below; not where FP64_P49 is exact and (k+1)*l > 8), FP64_P49, FP64, GOLDILOCKS,
- *              GOLDILOCKS_SPLIT whose bound holds
+ *   AUTO       the first of FP64_FFT (below; not where FP64_P49 is exact, (k+1)*l > 8 and the FFT kernel takes one
+ *              sample per team: N = 1024, and N = 512 with k = 1), FP64_P49, FP64, GOLDILOCKS, GOLDILOCKS_SPLIT whose
+ *              bound holds
  *              (env TFHE_HIP_BACKEND=fp64-fft|fp64-p49|fp64|goldilocks|goldilocks-split overrides AUTO). */
 #define TFHE_BACKEND_AUTO 0
 #define TFHE_BACKEND_GOLDILOCKS 1
@@ -95,7 +96,7 @@ int tfhe_params_validate(const tfhe_params *params);
 /* FP64_FFT: the negacyclic product through a complex FFT in fp64 (N/2 points, two coefficients per element,
  *            key split into 16-bit halves), exact by a proven bound on the rounding error of every output
  *            coefficient (csrc/field_fft.h: (3 n eta + sqrt 2 (R + 1) u) R M^1.5 |x| |y| < 1/4, e.g. 0.013 at N = 1024,
- *            k = 1, l = 3, log_base = 7); kernels at N = 512 and 1024.  Same bits as the exact-NTT fields. */
+ *            k = 1, l = 3, log_base = 7).  Same bits as the exact-NTT fields. */
 #define TFHE_BACKEND_FP64_FFT 5
 
 /* Creates a context bound to HIP device `device`.  Fails with TFHE_ERR_NO_DEVICE when no GPU is

@@ -20,7 +20,8 @@ from oracle import oracle as orc  # noqa: E402
 from test_emu_kernels import FFT_EDGE_SHAPES, extreme_operands, fft_error_bound  # noqa: E402
 
 # name, k, logN, (logB, levels), n of the blind rotation, aligned decomposer
-SHAPES = [("cfg1", 1, 9, (8, 2), 500, False), ("cfg2", 1, 10, (7, 3), 630, True), ("cfg3", 2, 9, (4, 6), 64, False)]
+SHAPES = [("cfg1", 1, 9, (8, 2), 500, False), ("cfg2", 1, 10, (7, 3), 630, True), ("cfg3", 2, 9, (4, 6), 64, False),
+          ("cfg5", 2, 11, (8, 4), 16, False)]
 # (log2 B does not divide 32 at the edge shapes: in the reference's literal mode a trivially encrypted accumulator then
 # decomposes to zeros -- SURVEY D4 -- so their blind rotations run with the aligned decomposer, like cfg2's)
 SHAPES += [(f"edge_N{1 << logn}_k{k}_B{pbs[0]}_l{pbs[1]}", k, logn, pbs, 16, 32 % pbs[0] != 0) for k, logn, pbs, _ in FFT_EDGE_SHAPES]

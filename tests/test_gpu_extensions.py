@@ -29,8 +29,6 @@ def test_aligned_decomposer_matches_oracle(oracle, k, logn, n, pbs, ks, backend)
     # (with the aligned decomposer the blind rotation at cfg2's shape really depends on the key: in the literal mode
     # the top four bits of a word are never decomposed, a trivial accumulator has nothing below them, every digit is
     # zero and the CMUXes leave it alone -- the external-product and keygen tests carry the arithmetic there)
-    if backend == "fp64-fft" and logn == 11:
-        pytest.skip("the complex-FFT backend has kernels at N = 512 and 1024")
     with m.Context(to_pkg_params(p), backend=BACKENDS[backend]) as ctx:
         ctx.set_decomposer_alignment(True)
         ctx.load_bootstrapping_key(bsk, ksk)

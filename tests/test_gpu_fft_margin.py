@@ -27,7 +27,7 @@ def test_rounding_margin_on_gfx950():
     assert run.returncode == 0, run.stderr[-2000:]
     rows = [json.loads(line) for line in run.stdout.splitlines() if line.startswith("{")]
     names = {r["shape"] for r in rows}
-    assert {"cfg1", "cfg2", "cfg3", "edge_N1024_k2_B11_l2", "edge_N512_k1_B13_l2"} <= names, names
+    assert {"cfg1", "cfg2", "cfg3", "cfg5", "edge_N1024_k2_B11_l2", "edge_N512_k1_B13_l2"} <= names, names
     for r in rows:
         assert r["exact"], r
         assert r["bound"] < 0.25, r

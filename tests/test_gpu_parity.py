@@ -246,17 +246,17 @@ def test_backend_selection(oracle):
     m = pkg()
     with m.Context(to_pkg_params(oracle.CFG2)) as ctx:  # N = 1024, rounding-error bound 0.011 < 1/4
         assert ctx.backend == "fp64-fft"
-    with pytest.raises(m.TfheError) as e:   # the complex transform's kernels exist at N = 512 and 1024
-        m.Context(to_pkg_params(oracle.CFG5), backend=m.BACKEND_FP64_FFT)
-    assert e.value.status == m.TFHE_ERR_UNSUPPORTED
+    with m.Context(to_pkg_params(oracle.CFG5)) as ctx:  # N = 2048: bound 0.17; two samples per team (round 3)
+        assert ctx.backend == "fp64-fft"
     with pytest.raises(m.TfheError) as e:   # N = 1024, 2 levels of 2^16: error bound 2.5 > 1/4
         m.Context(m.TfheParams(1, 10, 2, m.DecomposerParams(16, 2)), backend=m.BACKEND_FP64_FFT)
     assert e.value.status == m.TFHE_ERR_EXACTNESS
     with pytest.raises(m.TfheError) as e:   # 6 * 1024 * 2^7 * 2^31 = 2^50.6 > 2^48.25
         m.Context(to_pkg_params(oracle.CFG2), backend=m.BACKEND_FP64_P49)
     assert e.value.status == 7
-    # the reference's default parameters (18 * 512 * 2^4 * 2^31 = 2^48.17) fit the 49-bit field: AUTO
-    # takes it, and the four fields agree bit for bit on a batch
+    # the reference's default parameters (18 * 512 * 2^4 * 2^31 = 2^48.17) fit the 49-bit field, but the complex
+    # transform's teams take two samples at N = 512, k = 2 and AUTO prefers it (round 3); a shape where they take one
+    # (N = 1024, k = 1, 20 digit rows) stays with the 49-bit field.  All fields agree bit for bit on a batch
     p3 = oracle.CFG3
     lwe3, bsk3, ksk3, tv3 = oracle.synthetic_inputs(p3, 32, cfg_index=3)
     outs = {}
@@ -264,11 +264,13 @@ def test_backend_selection(oracle):
                     ("gls", m.BACKEND_GOLDILOCKS_SPLIT), ("p49", m.BACKEND_FP64_P49)):
         with m.Context(to_pkg_params(p3), backend=b) as ctx:
             if name == "auto":
-                assert ctx.backend == "fp64-p49"
+                assert ctx.backend == "fp64-fft"
             ctx.load_bootstrapping_key(bsk3, ksk3)
             outs[name] = ctx.bootstrap(lwe3, tv3)
     for name in ("fp64", "gl", "gls", "p49"):
         assert np.array_equal(outs[name], outs["auto"]), name
+    with m.Context(m.TfheParams(1, 10, 8, m.DecomposerParams(2, 10))) as ctx:
+        assert ctx.backend == "fp64-p49"
     wide = m.TfheParams(1, 11, 2, m.DecomposerParams(16, 2))  # 2 * 2048 * 2^16 * 2^15 = 2^43
     with m.Context(wide) as ctx:
         assert ctx.backend == "goldilocks"
@@ -638,8 +640,8 @@ def test_many_full_size_samples_against_the_oracle_on_all_host_cores(oracle, cfg
     assert not bad, f"{cfg}: rows {bad} differ from the oracle"
 
 
-@pytest.mark.parametrize("cfg,fast,count,slow_count", [("cfg3", "fp64-p49", 16384, 2048), ("cfg2", "fp64-fft", 8192, 2048),
-                                                       ("cfg5", "fp64-p42", 1024, 256), ("cfg1", "fp64-fft", 8192, 2048)])
+@pytest.mark.parametrize("cfg,fast,count,slow_count", [("cfg3", "fp64-fft", 16384, 2048), ("cfg2", "fp64-fft", 8192, 2048),
+                                                       ("cfg5", "fp64-fft", 1024, 256), ("cfg1", "fp64-fft", 8192, 2048)])
 def test_fields_agree_on_large_batches(oracle, cfg, fast, count, slow_count):
     """Independent arithmetic, same bits: `count` random full-size bootstraps in the field AUTO
     picks against the 42-bit fp64 field where AUTO picks another one, and the first `slow_count` of them against

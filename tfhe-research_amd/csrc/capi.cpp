@@ -314,7 +314,7 @@ int tfhe_context_create_with_backend(const tfhe_params* params, int device, int 
   const bool gl_ok = convolution_bits(params, GlField::key_bits()) < GlField::exact_bits();
   const bool gls_ok = convolution_bits(params, GlSplitField::key_bits()) < GlSplitField::exact_bits();
   // the complex transform is exact while the proven rounding error of an output coefficient stays below
-  // FftField::kMaxError (field_fft.h); its kernels exist at N = 512 and 1024
+  // FftField::kMaxError (field_fft.h)
   const bool fft_ok = launch::field_shape_supported(launch::kFieldFft, params->glwe_poly_degree) &&
                       params->pbs_decomposer.log_base <= (uint32_t)FftField::kMaxLogBase &&
                       FftField::error_bound((int)params->glwe_poly_degree,
@@ -329,13 +329,16 @@ int tfhe_context_create_with_backend(const tfhe_params* params, int device, int 
     else if (env && std::strcmp(env, "goldilocks-split") == 0) backend = TFHE_BACKEND_GOLDILOCKS_SPLIT;
     else if (env && std::strcmp(env, "fp64-fft") == 0) backend = TFHE_BACKEND_FP64_FFT;
   }
-  // AUTO: the complex transform first, except where the single-spectrum 49-bit field is exact and the product has
-  // many digit rows: then the key stream decides, and fp64-fft's two spectra per key polynomial make it twice as
-  // long (per 4096 bootstraps: the reference's default parameters, 18 rows: 145.7 ms against 77 ms; N = 1024, k = 1,
-  // l = 10, 20 rows: 150.7 against 125.2 ms; N = 512, k = 1, l = 4, 8 rows: 25.4 against 26.0 ms -- there it wins)
+  // AUTO: the complex transform first, except where the single-spectrum 49-bit field is exact, the product has many
+  // digit rows AND the complex transform's kernel takes one sample per team: then the key stream decides, and fp64-fft's
+  // two spectra per key polynomial make it twice as long (per 4096 bootstraps, N = 1024, k = 1, l = 10, 20 rows: 150.7
+  // against 125.2 ms; N = 512, k = 1, l = 4, 8 rows: 25.4 against 26.0 ms -- there it wins).  Where its teams take TWO
+  // samples (N = 512 with k = 2, N = 2048: kernels.hip::SamplesPerTeam) a key fetch serves two products and it wins
+  // with many rows too: the reference's default parameters (18 rows) 69.9 ms against 76.7 ms in the 49-bit field.
   const uint32_t digit_rows = (params->glwe_dimension + 1) * params->pbs_decomposer.levels;
+  const bool fft_pairs = launch::samples_per_team(launch::kFieldFft, params->glwe_poly_degree, params->glwe_dimension) > 1;
   if (backend == TFHE_BACKEND_AUTO)
-    field = (fft_ok && !(fp49_ok && digit_rows > 8)) ? launch::kFieldFft
+    field = (fft_ok && (fft_pairs || !(fp49_ok && digit_rows > 8))) ? launch::kFieldFft
             : fp49_ok ? launch::kFieldFp49
             : fp_ok ? launch::kFieldFp64
             : gl_ok ? launch::kFieldGoldilocks

@@ -38,8 +38,11 @@ struct GroupOf {
 // polynomial (8 elements per lane, one 6-wave team per CU: 137 ms per 1024 cfg5 bootstraps) and over four (4 elements
 // per lane, five register passes, 12 waves: 79.2 ms) but does not beat the 42-bit field's 77.2 ms -- a 12-wave team
 // is bound by its barriers, not its arithmetic (profiles/r02_kernel_ab.txt) -- so it is not instantiated.
+// the complex transform at N = 2048: over four waves per polynomial (4 elements per lane, five register passes) with
+// TWO samples per team -- 57.4 ms per 1024 cfg5 bootstraps against 77.5 ms for the 42-bit field and 80.1 ms with one
+// sample per team (profiles/r03_kernel_ab.txt); 0: not instantiated (round 2's state)
 #ifndef TFHE_FFT_N2048
-#define TFHE_FFT_N2048 0
+#define TFHE_FFT_N2048 1
 #endif
 template <class F, int LOGN>
 constexpr bool field_shape_ok() {
@@ -904,6 +907,13 @@ int field_parts(int field) { return (field == kFieldGoldilocks || field == kFiel
 
 bool field_shape_supported(int field, u32 log_n) {
   return field != kFieldFft || log_n == 9 || log_n == 10 || (TFHE_FFT_N2048 && log_n == 11);
+}
+
+int samples_per_team(int field, u32 log_n, u32 k) {
+  if (field != kFieldFft) return 1;
+  if (log_n == 11) return k == 2 ? SamplesPerTeam<FftField, 11, 2>::value : SamplesPerTeam<FftField, 11, 1>::value;
+  if (log_n == 9) return k == 2 ? SamplesPerTeam<FftField, 9, 2>::value : SamplesPerTeam<FftField, 9, 1>::value;
+  return 1;
 }
 
 // (field, log_n, k) -> template instantiation.  TFHE_DEV_CFG2_ONLY builds just the BASELINE cfg2

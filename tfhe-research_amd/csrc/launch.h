@@ -18,8 +18,10 @@ constexpr int kFieldFft = FftField::kId;                  // 5: complex FFT in f
 bool shape_supported(u32 log_n, u32 k);
 // spectra per key polynomial for a field (1 or 2)
 int field_parts(int field);
-// true if the field's kernels exist at this ring degree (the complex transform: N = 1024 only)
+// true if the field's kernels exist at this ring degree
 bool field_shape_supported(int field, u32 log_n);
+// samples a team of the blind-rotation kernel rotates at once for (field, log_n, k): 1 or 2
+int samples_per_team(int field, u32 log_n, u32 k);
 
 // twiddle table psi_rev[N] (8-byte field elements) must already be on the device;
 // spectra: poly_count x field_parts x N elements

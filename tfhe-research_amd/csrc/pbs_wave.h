@@ -252,7 +252,14 @@ TFHE_HD void external_product_team_multi(const Ctx& c, const PbsParams& P, const
 #ifndef TFHE_KEY_BUFFERS
 #define TFHE_KEY_BUFFERS 2
 #endif
-  constexpr int NB = TFHE_KEY_BUFFERS;  // staging buffers: chunk i + NB - 1 is fetched while chunk i is consumed
+  // staging buffers: chunk i + NB - 1 is fetched while chunk i is consumed.  Two everywhere (three and four measured
+  // nothing at one sample per team, profiles/r02_kernel_ab.txt) except the half-size chunks of two samples per team with
+  // one wave per polynomial: there a third buffer keeps the same bytes in flight as before (cfg3: 68.6 -> 63.8 ms; a
+  // fourth 65.9; at N = 2048 the third costs 31 more spilled registers: 57.3 -> 63.2 ms)
+#ifndef TFHE_KEY_BUFFERS_NS
+#define TFHE_KEY_BUFFERS_NS 3
+#endif
+  constexpr int NB = (NS > 1 && G == 1) ? TFHE_KEY_BUFFERS_NS : TFHE_KEY_BUFFERS;
   elem kbuf[NB][CH];
   // piece of the key a chunk index names: tile (source polynomial, accumulator) and offset inside it
   auto load_chunk = [&](u32 level, auto ci_c, int buf) {
