@@ -84,9 +84,7 @@ int tfhe_params_validate(const tfhe_params *params);
  *   GOLDILOCKS p = 2^64 - 2^32 + 1, u64 arithmetic; needs (k+1)*l * N * B * 2^32 < 2^62
  *   GOLDILOCKS_SPLIT  the same field with the key split into 16-bit halves; needs
  *              (k+1)*l * N * B * 2^15 < 2^62, which every base the reference can express satisfies
- *   AUTO       the first of FP64_FFT (below; not where FP64_P49 is exact, (k+1)*l > 8 and the FFT kernel takes one
- *              sample per team: N = 1024, and N = 512 with k = 1), FP64_P49, FP64, GOLDILOCKS, GOLDILOCKS_SPLIT whose
- *              bound holds
+ *   AUTO       the first of FP64_FFT (below), FP64_P49, FP64, GOLDILOCKS, GOLDILOCKS_SPLIT whose bound holds
  *              (env TFHE_HIP_BACKEND=fp64-fft|fp64-p49|fp64|goldilocks|goldilocks-split overrides AUTO). */
 #define TFHE_BACKEND_AUTO 0
 #define TFHE_BACKEND_GOLDILOCKS 1
@@ -134,7 +132,9 @@ int tfhe_load_bootstrapping_key_device(tfhe_context *ctx, const uint32_t *bsk, c
  * context into this mode (tfhe_bootstrap_batch, tfhe_blind_rotate_batch, the gates ... then run it);
  * loading an ordinary key switches back.  NOT the reference's bootstrap(): same plaintext, different
  * key material, different ciphertext bits (checked against oracle.bootstrap_bmmp instead).  Needs
- * even n and N = 512 (TFHE_ERR_UNSUPPORTED otherwise). */
+ * even n, N = 512 and a context in the GOLDILOCKS or FP64_P49 backend -- the fields where its three accumulator
+ * sets fit the registers: +10 % / -5 % against the loop there, 1.9-3.4x slower on 50-172 spilled registers in the
+ * two-spectra fields, where it is refused (TFHE_ERR_UNSUPPORTED otherwise, with the reason in tfhe_last_error). */
 int tfhe_load_bootstrapping_key_bmmp(tfhe_context *ctx, const uint32_t *bsk_bmmp, const uint32_t *ksk);
 int tfhe_load_bootstrapping_key_bmmp_device(tfhe_context *ctx, const uint32_t *bsk_bmmp, const uint32_t *ksk);
 /* 1 if the loaded key is a BMMP key */

@@ -140,7 +140,8 @@ int main() {
   // key_switching_works (key_switching.rs:118-159), ggsw external_product_works (ggsw.rs:203-240)
   {
     std::mt19937_64 gen(20261003);
-    Engine e2(tfhe_params);
+    // (the 49-bit prime field: one of the two backends that offer the unrolled blind rotation used below)
+    Engine e2(tfhe_params, 0, TFHE_BACKEND_FP64_P49);
     LweSecretKey lwe_secret_key = LweSecretKey::random(n, gen);
     GlweSecretKey glwe_secret_key = GlweSecretKey::random(tfhe_params, gen);
     BootstrappingKey bk = bootstrapping_key_gen(e2, lwe_secret_key, glwe_secret_key, gen);

@@ -109,6 +109,12 @@ def test_hip_path_vs_oracle_twin(oracle, k, n, pbs, log_p, backend):
     tv = oracle.construct_test_from_lut(p, rng.integers(0, 1 << log_p, size=1 << log_p))
     with ctx:
         assert not ctx.uses_bmmp
+        if ctx.backend not in ("goldilocks", "fp64-p49"):
+            # offered only where the three accumulator sets fit the registers (tfhe_hip.h): refused with a reason elsewhere
+            with pytest.raises(m.TfheError) as e:
+                ctx.load_bootstrapping_key_bmmp(bsk, ksk)
+            assert e.value.status == m.TFHE_ERR_UNSUPPORTED and "goldilocks" in str(e.value)
+            return
         ctx.load_bootstrapping_key_bmmp(bsk, ksk)
         assert ctx.uses_bmmp
         acc = ctx.blind_rotate(lwe, tv)
@@ -130,8 +136,8 @@ def test_hip_path_vs_oracle_twin(oracle, k, n, pbs, log_p, backend):
 @pytest.mark.gpu
 def test_bmmp_refused_where_it_is_not_offered(oracle):
     m = pkg()
-    for params in (m.TfheParams(1, 10, 4, m.DecomposerParams(7, 3)), m.TfheParams(2, 9, 5, m.DecomposerParams(4, 6))):
-        with m.Context(params) as ctx:
+    for params in (m.TfheParams(1, 10, 4, m.DecomposerParams(2, 8)), m.TfheParams(2, 9, 5, m.DecomposerParams(4, 6))):
+        with m.Context(params, backend=m.BACKEND_FP64_P49) as ctx:   # N = 1024; odd n
             with pytest.raises(m.TfheError) as e:
                 ctx.load_bootstrapping_key_bmmp(np.zeros(params.bsk_bmmp_shape(), dtype=np.uint32),
                                                 np.zeros(params.ksk_shape(), dtype=np.uint32))
@@ -145,7 +151,7 @@ def test_bmmp_with_gpu_generated_keys_at_the_reference_default_parameters(oracle
     m = pkg()
     p = oracle.CFG3
     rng = np.random.default_rng(12)
-    with m.Context(to_pkg_params(p)) as ctx:
+    with m.Context(to_pkg_params(p), backend=m.BACKEND_FP64_P49) as ctx:
         lwe_sk, glwe_sk, bsk, ksk = ctx.generate_keys(rng, bmmp=True)
         assert ctx.uses_bmmp and bsk.shape == oracle.bmmp_bsk_shape(p)
         bits = rng.integers(0, 2, size=(256, 2))

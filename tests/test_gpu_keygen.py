@@ -49,6 +49,8 @@ def test_encryption_entry_points_match_oracle(oracle, shape, backend):
     p = oracle.Params(k, logn, n, oracle.Decomposer(*pbs), oracle.Decomposer(*ks), log_p=log_p)
     if backend == "fp64" and not (np.log2(p.R) + logn + pbs[0] + 15 < 40.9 and pbs[0] <= 9):
         pytest.skip("outside the fp64 backend's exactness bound")  # "auto" is the 49-bit field at ref_test
+    if backend == "fp64-fft" and pbs[0] > 13:
+        pytest.skip("outside the fp64-fft backend's rounding-error bound (tfhe_context_create refuses it)")
     rng = np.random.default_rng(1000 * logn + 10 * k + n)
     glwe_sk = rng.integers(0, 2, size=(k, p.N)).astype(np.uint32)
     lwe_sk = rng.integers(0, 2, size=n).astype(np.uint32)

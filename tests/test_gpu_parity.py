@@ -254,9 +254,9 @@ def test_backend_selection(oracle):
     with pytest.raises(m.TfheError) as e:   # 6 * 1024 * 2^7 * 2^31 = 2^50.6 > 2^48.25
         m.Context(to_pkg_params(oracle.CFG2), backend=m.BACKEND_FP64_P49)
     assert e.value.status == 7
-    # the reference's default parameters (18 * 512 * 2^4 * 2^31 = 2^48.17) fit the 49-bit field, but the complex
-    # transform's teams take two samples at N = 512, k = 2 and AUTO prefers it (round 3); a shape where they take one
-    # (N = 1024, k = 1, 20 digit rows) stays with the 49-bit field.  All fields agree bit for bit on a batch
+    # the reference's default parameters (18 * 512 * 2^4 * 2^31 = 2^48.17) fit the 49-bit field, but AUTO takes the
+    # complex transform wherever its rounding bound holds (since round 3 it is ahead with many digit rows too).  All
+    # fields agree bit for bit on a batch
     p3 = oracle.CFG3
     lwe3, bsk3, ksk3, tv3 = oracle.synthetic_inputs(p3, 32, cfg_index=3)
     outs = {}
@@ -269,8 +269,8 @@ def test_backend_selection(oracle):
             outs[name] = ctx.bootstrap(lwe3, tv3)
     for name in ("fp64", "gl", "gls", "p49"):
         assert np.array_equal(outs[name], outs["auto"]), name
-    with m.Context(m.TfheParams(1, 10, 8, m.DecomposerParams(2, 10))) as ctx:
-        assert ctx.backend == "fp64-p49"
+    with m.Context(m.TfheParams(1, 10, 8, m.DecomposerParams(2, 10))) as ctx:   # 20 digit rows: still the complex transform
+        assert ctx.backend == "fp64-fft"
     wide = m.TfheParams(1, 11, 2, m.DecomposerParams(16, 2))  # 2 * 2048 * 2^16 * 2^15 = 2^43
     with m.Context(wide) as ctx:
         assert ctx.backend == "goldilocks"

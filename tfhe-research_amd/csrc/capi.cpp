@@ -329,16 +329,14 @@ int tfhe_context_create_with_backend(const tfhe_params* params, int device, int 
     else if (env && std::strcmp(env, "goldilocks-split") == 0) backend = TFHE_BACKEND_GOLDILOCKS_SPLIT;
     else if (env && std::strcmp(env, "fp64-fft") == 0) backend = TFHE_BACKEND_FP64_FFT;
   }
-  // AUTO: the complex transform first, except where the single-spectrum 49-bit field is exact, the product has many
-  // digit rows AND the complex transform's kernel takes one sample per team: then the key stream decides, and fp64-fft's
-  // two spectra per key polynomial make it twice as long (per 4096 bootstraps, N = 1024, k = 1, l = 10, 20 rows: 150.7
-  // against 125.2 ms; N = 512, k = 1, l = 4, 8 rows: 25.4 against 26.0 ms -- there it wins).  Where its teams take TWO
-  // samples (N = 512 with k = 2, N = 2048: kernels.hip::SamplesPerTeam) a key fetch serves two products and it wins
-  // with many rows too: the reference's default parameters (18 rows) 69.9 ms against 76.7 ms in the 49-bit field.
-  const uint32_t digit_rows = (params->glwe_dimension + 1) * params->pbs_decomposer.levels;
-  const bool fft_pairs = launch::samples_per_team(launch::kFieldFft, params->glwe_poly_degree, params->glwe_dimension) > 1;
+  // AUTO: the complex transform wherever its rounding bound holds.  (Round 2 kept the single-spectrum 49-bit field for
+  // products of more than 8 digit rows, where fp64-fft's two spectra per key polynomial made the key stream decide.
+  // Since round 3 -- six-FMA butterflies, twiddles fetched a transpose ahead, two samples per team at N = 512 with
+  // k = 2 and at N = 2048 -- it is ahead or level there too, blind rotation of 2048 samples, profiles/r03_auto_choice.txt:
+  // the reference's default parameters (18 rows) 37.5 against 40.8 ms; N = 1024, k = 1, l = 10 (20 rows) 58.2 against
+  // 65.3; N = 512, k = 1, l = 6 (12 rows) 19.8 against 20.0; N = 2048, k = 2, l = 5 (15 rows, 512 samples) 34.3 against 34.2.)
   if (backend == TFHE_BACKEND_AUTO)
-    field = (fft_ok && (fft_pairs || !(fp49_ok && digit_rows > 8))) ? launch::kFieldFft
+    field = fft_ok ? launch::kFieldFft
             : fp49_ok ? launch::kFieldFp49
             : fp_ok ? launch::kFieldFp64
             : gl_ok ? launch::kFieldGoldilocks
@@ -586,6 +584,12 @@ static size_t key_ggsws(const tfhe_context* ctx, bool bmmp) {
 static int check_bmmp(tfhe_context* ctx) {
   if (!launch::shape_supported_bmmp(ctx->pbs.log_n, ctx->pbs.k) || (ctx->params.lwe_dimension & 1u))
     return fail(ctx, TFHE_ERR_UNSUPPORTED, "the unrolled (BMMP) blind rotation needs N = 512 and an even lwe_dimension");
+  if (!launch::field_supported_bmmp(ctx->field))
+    return fail(ctx, TFHE_ERR_UNSUPPORTED,
+                std::string("the unrolled (BMMP) blind rotation is offered in the goldilocks and fp64-p49 backends only (its three "
+                            "accumulator sets spill 50-172 registers in the others and it runs slower than the loop there); this "
+                            "context uses ") + tfhe_context_backend(ctx) + ": create it with TFHE_BACKEND_GOLDILOCKS or "
+                            "TFHE_BACKEND_FP64_P49, or load an ordinary key");
   return TFHE_OK;
 }
 

@@ -794,8 +794,8 @@ template <class F, int LOGN, int K>
 hipError_t launch_blind_rotate_bmmp(hipStream_t s, const PbsParams& P, const void* tw_v, const u32* lwe_in,
                                     size_t batch, const u32* tv, size_t tv_stride, const void* bsk_v,
                                     u32* glwe_out, u32* lwe_extracted) {
-  if constexpr (LOGN != 9 || !field_shape_ok<F, LOGN>()) {
-    return hipErrorInvalidValue;  // shape_supported_bmmp() keeps callers away
+  if constexpr (LOGN != 9 || !field_shape_ok<F, LOGN>() || !(F::kId == GlField::kId || F::kId == Fp49Field::kId)) {
+    return hipErrorInvalidValue;  // shape_supported_bmmp() / field_supported_bmmp() keep callers away
   } else {
     using C = TeamCfg<F, LOGN, K, 1>;
     auto tw = static_cast<const typename F::elem*>(tw_v);
@@ -902,6 +902,12 @@ namespace launch {
 bool shape_supported(u32 log_n, u32 k) { return log_n >= 9 && log_n <= 11 && (k == 1 || k == 2); }
 
 bool shape_supported_bmmp(u32 log_n, u32 k) { return log_n == 9 && (k == 1 || k == 2); }
+
+// The unrolled blind rotation carries three accumulator sets per wave.  Offered where that fits the registers and the
+// mode is at least even with the loop: Goldilocks (+10 % at the reference's default parameters) and the single-spectrum
+// 49-bit field (-5 %, 17-23 spilled registers).  In the two-spectra fields it ran 1.9-3.4x slower than the loop on 50-172
+// spilled registers (profiles/r02_kernel_ab.txt, r02_h_isa_resources_all_kernels.txt): not instantiated, refused at load.
+bool field_supported_bmmp(int field) { return field == kFieldGoldilocks || field == kFieldFp49; }
 
 int field_parts(int field) { return (field == kFieldGoldilocks || field == kFieldFp49) ? 1 : 2; }
 

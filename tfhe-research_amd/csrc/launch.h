@@ -37,6 +37,7 @@ hipError_t blind_rotate(hipStream_t s, int field, const PbsParams& P, const void
 // The unrolled blind rotation of notes/BMMP Bootstrapping.md (two key bits per step): bsk holds
 // n/2 * 3 prepared GGSWs (pbs_wave.h::blind_rotate_bmmp_team); n even, shape_supported_bmmp only.
 bool shape_supported_bmmp(u32 log_n, u32 k);
+bool field_supported_bmmp(int field);  // Goldilocks and fp64-p49: the fields whose BMMP kernel does not lose to the loop
 hipError_t blind_rotate_bmmp(hipStream_t s, int field, const PbsParams& P, const void* tw,
                              const u32* lwe_in, size_t batch, const u32* tv, size_t tv_stride,
                              const void* bsk, u32* glwe_out, u32* lwe_extracted);

@@ -18,7 +18,7 @@ rw = lambda *s: torch.randint(-(1 << 31), (1 << 31) - 1, s, dtype=torch.int32, d
 lw, kk = rw(batch, n + 1), rw(*P.ksk_shape())
 keys = {"loop": rw(*P.bsk_shape()), "bmmp": rw(*P.bsk_bmmp_shape())}
 tvd = torch.from_numpy(m.construct_identity_test_vector(P).astype(np.int32)).to(dev)
-for name, be in (("auto", m.BACKEND_AUTO), ("fp64-p42", m.BACKEND_FP64), ("goldilocks", m.BACKEND_GOLDILOCKS)):
+for name, be in (("fp64-p49", m.BACKEND_FP64_P49), ("goldilocks", m.BACKEND_GOLDILOCKS)):  # the backends that offer BMMP
     try:
         ctx = m.Context(P, backend=be)
     except m.TfheError:
