@@ -1,5 +1,5 @@
 # GPU box, end-of-round evidence (run from the repo root through gpurun): bench lines of every workload, rocprofv3
-# kernel stats of the default bench command, PMC passes for the blind-rotation kernel (cfg2) and the standalone
+# kernel stats of the default bench command, PMC passes for the blind-rotation kernel (cfg2, cfg5, cfg3) and the standalone
 # external product.  Everything lands under gpurun_out/final/; copy what is to be judged into profiles/.
 set -u
 cd $GRAFT_REPO_ROOT
@@ -14,10 +14,13 @@ python bench.py --workload cfg1 --steps 5 --warmup 2 --no-cpu-baseline > $O/benc
 python bench.py --kernel external_product --no-cpu-baseline > $O/bench_ep_shared.json.log 2>&1 && \
 python bench.py --kernel external_product --batch 65536 --no-cpu-baseline > $O/bench_ep_shared_64k.json.log 2>&1 && \
 python bench.py --kernel external_product --ggsw-per-sample --no-cpu-baseline > $O/bench_ep_streamed.json.log 2>&1 && \
+python bench.py --pool-devices 0 --steps 5 --warmup 2 > $O/bench_pool_1member.json.log 2>&1 && \
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_cfg2_torchrun1.json.log 2>&1 && \
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/stats.log 2>&1) && \
 find $O/stats -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_cfg2.csv \; && head -5 $O/kernel_stats_cfg2.csv && \
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats_ep -- python3 $GRAFT_REPO_ROOT/bench.py --kernel external_product --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/stats_ep.log 2>&1) && \
 find $O/stats_ep -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_ep.csv \; && head -4 $O/kernel_stats_ep.csv && \
 KERNEL_REGEX=blind_rotate bash tools/profile_pmc.sh final/pmc && \
+KERNEL_REGEX=blind_rotate BENCH_ARGS="--workload cfg5" bash tools/profile_pmc.sh final/pmc_cfg5 && \
+KERNEL_REGEX=blind_rotate BENCH_ARGS="--workload cfg3" bash tools/profile_pmc.sh final/pmc_cfg3 && \
 KERNEL_REGEX=external_product BENCH_ARGS="--kernel external_product" bash tools/profile_pmc.sh final/pmc_ep

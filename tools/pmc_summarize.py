@@ -9,8 +9,11 @@ profiles/ (plus, with --json, the traffic figure bench.py reports in roofline.tr
 """
 import csv
 import json
+import os
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 d, label, batch, n, algo_bytes = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
 want = sys.argv[sys.argv.index("--kernel") + 1] if "--kernel" in sys.argv else "blind_rotate"
@@ -55,7 +58,11 @@ if "SQ_INSTS_VALU" in per:
 if "GRBM_GUI_ACTIVE" in per and "SQ_INSTS_VALU" in per:
     cyc = per["GRBM_GUI_ACTIVE"] / 8  # summed over the 8 XCDs
     print(f"# derived: kernel = {cyc / 1e6:.1f} M cycles; cycles per VALU instruction per SIMD = "
-          f"{cyc * 1024 / per['SQ_INSTS_VALU']:.2f}")
+          f"{cyc * 1024 / per['SQ_INSTS_VALU']:.2f} (issue floor of this mix {FLOOR:.2f}: VALU issue at {min(1.0, FLOOR * per['SQ_INSTS_VALU'] / (cyc * 1024)):.2f})")
+if "SQ_WAIT_ANY" in per and "SQ_WAVE_CYCLES" in per:
+    print(f"# derived: SQ_WAIT_ANY / SQ_WAVE_CYCLES = {per['SQ_WAIT_ANY'] / per['SQ_WAVE_CYCLES']:.2f} (share of a wave's cycles parked in s_waitcnt / barriers)")
+if "SQ_INSTS_VMEM_RD" in per:
+    print(f"# derived: vector-memory read instructions per external product = {per['SQ_INSTS_VMEM_RD'] / products:.1f}")
 if "--json" in sys.argv and "FETCH_SIZE" in per and "WRITE_SIZE" in per:
     out = sys.argv[sys.argv.index("--json") + 1]
     valu = {}
@@ -69,7 +76,8 @@ if "--json" in sys.argv and "FETCH_SIZE" in per and "WRITE_SIZE" in per:
                                 "weighted with the shipped kernel's instruction mix (profiles/r02_*_isa_blind_rotate_loops.txt): "
                                 + ",".join(str(x) for x in MIX) + " fma,mul,add,rndne,cvt,integer per wave and iteration"}
     # bench.py matches on "workload" == "<name> batch <batch>": keep it to exactly that
-    json.dump({"kernel": BENCH_KERNEL, "workload": label.split(",")[0], "valu": valu,
+    from bench import kernel_source_hash  # the kernels this record was measured on: bench.py refuses it for any other
+    json.dump({"kernel": BENCH_KERNEL, "workload": label.split(",")[0], "kernel_source_hash": kernel_source_hash(), "valu": valu,
                "fetch_size_kib": per["FETCH_SIZE"], "write_size_kib": per["WRITE_SIZE"],
                "traffic_bytes_per_launch": traffic,
                "note": "L2 fabric-side requests (Infinity-Cache hits included); varies with the drift of the teams inside an XCD",
