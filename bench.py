@@ -356,6 +356,9 @@ def main():
     ap.add_argument("--pool-devices", default="",
                     help="comma-separated HIP device ordinals: time the multi-GPU pool of the C ABI (tfhe_pool_*) in ONE "
                          "process instead of one process per GPU, e.g. 0,1,2,3,4,5,6,7 (0,0 rehearses it on one GPU)")
+    ap.add_argument("--no-secondary-legs", action="store_true",
+                    help="skip the figures taken after the timed region (aligned decomposer, exact prime-field backend): for "
+                         "rocprofv3 --stats runs whose per-kernel averages should contain the timed launches only")
     ap.add_argument("--gate", default="", choices=["", "nand", "and", "or", "xor"],
                     help="step = one homomorphic gate over the batch (boolean.rs: bootstrap(2*ct1 + ct0)) instead of a plain PBS")
     args = ap.parse_args()
@@ -573,7 +576,7 @@ def main():
             "ms_per_step": float(t_sg.item()) / sg_steps * 1e3,
             "what": f"rank 0 holds all {batch * world} ciphertexts: isend/recv scatter of {batch * (n + 1) * 4 / 1e6:.0f} MB per peer "
                     "over RCCL/xGMI, local bootstrap, gather back; NOT the headline value"}
-    if not args.gate and not args.scatter_gather and pbs[0] * (32 // pbs[0]) != 32:
+    if not args.gate and not args.scatter_gather and not args.no_secondary_legs and pbs[0] * (32 // pbs[0]) != 32:
         # log2 B does not divide 32 (cfg2: 7): with the reference's literal decomposer the top 32 mod log2 B bits of a
         # word are never decomposed, a trivially encrypted accumulator has no bit below them, every digit is zero and
         # the blind rotation never depends on the key -- in the reference too (decomposer.rs:42-80).  The
@@ -602,7 +605,7 @@ def main():
         except Exception as e:  # noqa: BLE001 - a secondary figure must not lose the benchmark line
             result["aligned_decomposer"] = {"error": str(e)}
     ctx.close()
-    if world == 1 and backend_name == "fp64-fft" and not args.gate and args.backend == "auto":
+    if world == 1 and backend_name == "fp64-fft" and not args.gate and args.backend == "auto" and not args.no_secondary_legs:
         # beside the headline (never instead of it): the same step in the exact prime-field NTT the complex-FFT backend
         # replaced as the default (same ciphertexts and key-switching key, a fresh random bootstrapping key: the time does
         # not depend on the data), so that both arithmetic routes are in one record

@@ -18,6 +18,8 @@ python bench.py --pool-devices 0 --steps 5 --warmup 2 > $O/bench_pool_1member.js
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_cfg2_torchrun1.json.log 2>&1 && \
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/stats.log 2>&1) && \
 find $O/stats -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_cfg2.csv \; && head -5 $O/kernel_stats_cfg2.csv && \
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats_timed -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary-legs > $GRAFT_REPO_ROOT/$O/stats_timed.log 2>&1) && \
+find $O/stats_timed -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_cfg2_timed_only.csv \; && head -3 $O/kernel_stats_cfg2_timed_only.csv && \
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats_ep -- python3 $GRAFT_REPO_ROOT/bench.py --kernel external_product --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/stats_ep.log 2>&1) && \
 find $O/stats_ep -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_ep.csv \; && head -4 $O/kernel_stats_ep.csv && \
 KERNEL_REGEX=blind_rotate bash tools/profile_pmc.sh final/pmc && \
