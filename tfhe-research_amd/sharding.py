@@ -29,18 +29,22 @@ def scatter_rows(full, root: int = 0, *, batch: Optional[int] = None, width: Opt
         batch, width, like = full.shape[0], full.shape[1], full
     start, stop = shard_range(batch, world, rank)
     mine = torch.empty((stop - start, width), dtype=like.dtype, device=like.device)
+    # one grouped point-to-point exchange (dist.batch_isend_irecv = one ncclGroupStart/End on RCCL): the root's sends to
+    # its peers are posted together and travel over the peers' xGMI links at the same time, instead of one isend after
+    # the other on one communicator
+    ops = []
     if rank == root:
-        reqs = []
         for r in range(world):
             s, e = shard_range(batch, world, r)
             if r == root:
                 mine.copy_(full[s:e])
             elif e > s:
-                reqs.append(dist.isend(full[s:e].contiguous(), dst=r))
-        for q in reqs:
-            q.wait()
+                ops.append(dist.P2POp(dist.isend, full[s:e].contiguous(), r))
     elif stop > start:
-        dist.recv(mine, src=root)
+        ops.append(dist.P2POp(dist.irecv, mine, root))
+    if ops:
+        for q in dist.batch_isend_irecv(ops):
+            q.wait()
     return mine
 
 
@@ -49,17 +53,21 @@ def gather_rows(mine, batch: int, root: int = 0):
     import torch
     import torch.distributed as dist
     world, rank = dist.get_world_size(), dist.get_rank()
+    ops, full = [], None
     if rank != root:
         if mine.shape[0]:
-            dist.send(mine.contiguous(), dst=root)
-        return None
-    full = torch.empty((batch, mine.shape[1]), dtype=mine.dtype, device=mine.device)
-    for r in range(world):
-        s, e = shard_range(batch, world, r)
-        if r == root:
-            full[s:e].copy_(mine)
-        elif e > s:
-            dist.recv(full[s:e], src=r)
+            ops.append(dist.P2POp(dist.isend, mine.contiguous(), root))
+    else:
+        full = torch.empty((batch, mine.shape[1]), dtype=mine.dtype, device=mine.device)
+        for r in range(world):
+            s, e = shard_range(batch, world, r)
+            if r == root:
+                full[s:e].copy_(mine)
+            elif e > s:
+                ops.append(dist.P2POp(dist.irecv, full[s:e], r))  # a contiguous row slice: received in place
+    if ops:  # grouped like the scatter: the peers' sends arrive over their own links at the same time
+        for q in dist.batch_isend_irecv(ops):
+            q.wait()
     return full
 
 
