@@ -112,7 +112,13 @@ struct DeviceWave {
   // 8 barriers that only order a group's cross-wave transposes was built and measured: bit-exact, same
   // time (78.88 vs 78.95 ms) -- the wait is the drift between waves that share SIMDs three at a time,
   // whatever the scope.  profiles/r02_kernel_ab.txt)
-  __device__ __forceinline__ void team_sync() const { __syncthreads(); }
+  // (TFHE_PROBE_NO_TEAM_SYNC: timing probe, WRONG BITS -- the team barriers compiled out.  Dev builds only.)
+#ifndef TFHE_PROBE_NO_TEAM_SYNC
+#define TFHE_PROBE_NO_TEAM_SYNC 0
+#endif
+  __device__ __forceinline__ void team_sync() const {
+    if (!TFHE_PROBE_NO_TEAM_SYNC) __syncthreads();
+  }
   __device__ __forceinline__ Elem* scratch() const { return scratch_; }
   __device__ __forceinline__ const Elem* scratch_of(int s) const {
     return reinterpret_cast<const Elem*>(team_base_ + (size_t)s * group_stride_);

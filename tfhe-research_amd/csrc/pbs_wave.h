@@ -237,8 +237,14 @@ TFHE_HD void external_product_team_multi(const Ctx& c, const PbsParams& P, const
   constexpr int CH = E < CH_MAX ? E : CH_MAX;
   constexpr int CHUNKS = TILES * (E / CH);
   // tile of source polynomial sp and accumulator a = (key m, part q)
+  // (TFHE_PROBE_HOT_KEY: timing probe, WRONG BITS -- every key chunk is read from the first 4 KiB of the key, i.e. from
+  // the vector L1: what is left is the kernel without its key stream.  Dev builds only, never the shipped library.)
+#ifndef TFHE_PROBE_HOT_KEY
+#define TFHE_PROBE_HOT_KEY 0
+#endif
   auto tile_ptr = [&](u32 level, int sp, int a) -> const elem* {
     const int m = a / PARTS, q = a % PARTS;
+    if (TFHE_PROBE_HOT_KEY) return ggsw;
     return ggsw + (size_t)m * ggsw_words + (((size_t)(sp * P.levels + level) * (K + 1) + me) * PARTS + q) * N;
   };
   // Spectrum exchange through LDS.  With ONE buffer per group a level needs two team barriers
@@ -268,7 +274,8 @@ TFHE_HD void external_product_team_multi(const Ctx& c, const PbsParams& P, const
     constexpr int q = ci % ACCS, r0 = ((ci / ACCS) % PIECES) * CH, src_poly = ci / (ACCS * PIECES);
     const elem* tile = tile_ptr(level, src_poly, q);
 #pragma unroll
-    for (int r = 0; r < CH; ++r) kbuf[buf][r] = tile[spectrum_slot<LT, G, (int)sizeof(elem)>(lane, r0 + r)];
+    for (int r = 0; r < CH; ++r)
+      kbuf[buf][r] = tile[TFHE_PROBE_HOT_KEY ? (lane & 63) + r : spectrum_slot<LT, G, (int)sizeof(elem)>(lane, r0 + r)];
   };
   // the contexts of the samples' buffers (NS == 1: the level's parity buffer, see above)
   auto buffers_of_level = [&](u32 t, Ctx (&cl)[NS]) {
