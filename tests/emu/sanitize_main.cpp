@@ -20,7 +20,8 @@ int main() {
     for (const Shape& s : shapes) {
       for (int field = 1; field <= 5; ++field) {
         if (field == 2 && s.log_base > 9) continue;  // outside the fp64 field's small-digit bound
-        if (field == 5 && !(s.logn == 9 || s.logn == 10)) continue;  // complex transform: the shapes the GPU library ships (N = 512, 1024)
+        // complex transform: the shapes the GPU library ships (N = 512, 1024; N = 2048 over four waves), inside its bound
+        if (field == 5 && (!(s.logn == 9 || s.logn == 10 || (s.logn == 11 && s.g == 4)) || s.log_base > 13)) continue;
         // 49-bit field: only where (k+1) l N B 2^31 < 2^48.25 (here: the reference default shape)
         if (field == 4 && !(s.logn == 9 && s.k == 2 && s.log_base == 4)) continue;
         const size_t N = (size_t)1 << s.logn, R = (size_t)(s.k + 1) * s.levels, n = 3;
@@ -35,6 +36,19 @@ int main() {
         if (emu_external_product(field, s.g, s.k, s.logn, s.log_base, s.levels, spec.data(), glwe.data(), out.data())) return 3;
         if (emu_blind_rotate(field, s.g, (u32)n, s.k, s.logn, 2, 1, s.log_base, s.levels, 2, lwe.data(), tv.data(), 0,
                              spec.data(), acc.data(), ext.data())) return 4;
+        // two samples per team (the complex transform's kernels at N = 512 with k = 2 and at N = 2048): odd batch of 3,
+        // per-sample test vectors
+        if (field == 5 && exb == 1 && (s.logn == 11 || (s.logn == 9 && s.k == 2))) {
+          std::vector<u32> lwe3(3 * (n + 1)), tv3(3 * N), acc3(3 * (s.k + 1) * N), ext3(3 * (s.k * N + 1));
+          fill(lwe3);
+          for (auto& x : tv3) x = (u32)(gen() & 3u);
+          emu_set_samples_per_team(2);
+          const int rc = emu_blind_rotate(field, s.g, (u32)n, s.k, s.logn, 2, 1, s.log_base, s.levels, 3, lwe3.data(), tv3.data(), N,
+                                          spec.data(), acc3.data(), ext3.data());
+          emu_set_samples_per_team(1);
+          if (rc) return 6;
+          std::printf("ok two samples per team logn=%d g=%d k=%u\n", s.logn, s.g, s.k);
+        }
         std::vector<u32> rows(2 * (s.k + 1) * N);
         fill(rows);
         if (emu_glwe_body(field, s.logn, s.g, s.k, 2, rows.data(), sk.data(), body.data(), 0)) return 5;
