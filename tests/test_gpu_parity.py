@@ -562,13 +562,24 @@ def test_device_entry_points_are_graph_capturable(oracle):
     assert np.array_equal(eager[2], oracle.bootstrap(p, lwe[2], bsk, ksk, tv))
 
 
-def test_batch_edge_cases(oracle, contexts):
-    """batch of 1, odd batches, and the empty batch (refused with a status, never a crash)."""
-    p, ctx, lwe, bsk, ksk, tv = contexts("cfg2_small", "auto")
+@pytest.mark.parametrize("name", ["cfg2_small", "ref_test", "cfg5_small"])
+def test_batch_edge_cases(oracle, contexts, name):
+    """batch of 1, odd batches, and the empty batch (refused with a status, never a crash).  ref_test and cfg5_small
+    are shapes whose teams rotate TWO samples at once (N = 512 with k = 2, N = 2048): a batch of 1 and every odd batch
+    leave the last team one sample short -- it redoes its last sample in the free slot and must write it once; per-sample
+    test vectors and the blind-rotation output ([batch][k+1][N], written per sample) go through the same slots."""
+    p, ctx, lwe, bsk, ksk, tv = contexts(name, "auto")
     m = pkg()
     full = ctx.bootstrap(lwe, tv)
+    acc = ctx.blind_rotate(lwe, tv)
+    tvs = np.stack([np.roll(tv, 3 * b) for b in range(lwe.shape[0])])
+    per = ctx.bootstrap(lwe, tvs)
+    for b in (0, lwe.shape[0] - 1):
+        assert np.array_equal(per[b], oracle.bootstrap(p, lwe[b], bsk, ksk, tvs[b])), b
     for size in (1, 2, 3, 7):
         assert np.array_equal(ctx.bootstrap(lwe[:size], tv), full[:size])
+        assert np.array_equal(ctx.blind_rotate(lwe[:size], tv), acc[:size])
+        assert np.array_equal(ctx.bootstrap(lwe[:size], tvs[:size]), per[:size])
     with pytest.raises(m.TfheError) as e:
         ctx.bootstrap(np.zeros((0, p.n + 1), dtype=np.uint32), tv)
     assert e.value.status == 5
