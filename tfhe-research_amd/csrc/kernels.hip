@@ -25,11 +25,17 @@ namespace {
 #endif
 // (N = 1024 over two waves was measured too: 97.9 ms against 64.0 ms per cfg2 batch -- a fourth
 // register pass and cross-wave barriers cost more than the third wave per SIMD gives.)
+// (experiment flag: the complex transform at N = 1024 over two waves per polynomial -- 4 elements per lane, registers
+// for two samples per team; profiles/r03_kernel_ab.txt)
+#ifndef TFHE_GROUP_N1024_FFT
+#define TFHE_GROUP_N1024_FFT 1
+#endif
 template <class F, int LOGN>
 struct GroupOf {
   // the complex transform has N/2 elements of 16 bytes: two waves per polynomial at N = 2048 hold 8 of
   // them per lane and array (the register footprint of one wave at N = 1024)
-  static constexpr int value = (LOGN >= 11) ? (F::kLogShrink ? TFHE_GROUP_N2048_FFT : TFHE_GROUP_N2048) : 1;
+  static constexpr int value = (LOGN >= 11) ? (F::kLogShrink ? TFHE_GROUP_N2048_FFT : TFHE_GROUP_N2048)
+                               : (LOGN == 10 && F::kLogShrink) ? TFHE_GROUP_N1024_FFT : 1;
 };
 
 // Shapes a transform policy is instantiated for.  The complex transform (field_fft.h) holds two
@@ -169,9 +175,13 @@ struct ExchangeBuffersOf {
 #ifndef TFHE_NS_N512_K1
 #define TFHE_NS_N512_K1 1
 #endif
+#ifndef TFHE_NS_N1024
+#define TFHE_NS_N1024 1
+#endif
 template <class F, int LOGN, int K>
 struct SamplesPerTeam {
-  static constexpr int value = !F::kLogShrink ? 1 : LOGN == 11 ? TFHE_NS_N2048 : LOGN == 9 ? (K == 2 ? TFHE_NS_N512_K2 : TFHE_NS_N512_K1) : 1;
+  static constexpr int value = !F::kLogShrink ? 1 : LOGN == 11 ? TFHE_NS_N2048 : LOGN == 9 ? (K == 2 ? TFHE_NS_N512_K2 : TFHE_NS_N512_K1)
+                               : LOGN == 10 ? TFHE_NS_N1024 : 1;
 };
 
 template <class F, int LOGN, int K, int NS_ = SamplesPerTeam<F, LOGN, K>::value>
