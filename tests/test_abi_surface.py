@@ -58,6 +58,31 @@ def test_no_cpu_fallback():
     assert e.value.status == 6  # TFHE_ERR_NO_DEVICE
 
 
+def test_pool_has_no_cpu_fallback_and_checks_its_arguments():
+    """The multi-GPU pool of the C ABI (tfhe_pool_*): refuses bad arguments with a status, fails with
+    TFHE_ERR_NO_DEVICE when no GPU is present (vacuous on a GPU box), and NULL handles are harmless."""
+    import torch
+    m = pkg()
+    lib = m.lib()
+    lib.tfhe_pool_size.restype = C.c_size_t
+    lib.tfhe_pool_last_error.restype = C.c_char_p
+    params = m.TfheParams(1, 10, 630, m.DecomposerParams(7, 3))._c()
+    out = C.c_void_p()
+    one = (C.c_int * 1)(0)
+    assert lib.tfhe_pool_create(None, one, C.c_size_t(1), C.c_int(0), C.byref(out)) == m.TFHE_ERR_INVALID_ARGUMENT
+    assert lib.tfhe_pool_create(C.byref(params), one, C.c_size_t(0), C.c_int(0), C.byref(out)) == m.TFHE_ERR_INVALID_ARGUMENT
+    assert lib.tfhe_pool_create(C.byref(params), None, C.c_size_t(1), C.c_int(0), C.byref(out)) == m.TFHE_ERR_INVALID_ARGUMENT
+    assert lib.tfhe_pool_size(None) == 0 and lib.tfhe_pool_last_error(None) == b""
+    assert lib.tfhe_pool_synchronize(None) == m.TFHE_ERR_INVALID_ARGUMENT
+    lib.tfhe_pool_destroy(None)
+    bad = m.TfheParams(1, 10, 630, m.DecomposerParams(7, 5))._c()   # levels > floor(32/7): the reference would not terminate
+    assert lib.tfhe_pool_create(C.byref(bad), one, C.c_size_t(1), C.c_int(0), C.byref(out)) == m.TFHE_ERR_INVALID_PARAMS
+    if not torch.cuda.is_available():
+        with pytest.raises(m.TfheError) as e:
+            m.Pool(m.TfheParams(1, 10, 630, m.DecomposerParams(7, 3)), [0, 1])
+        assert e.value.status == m.TFHE_ERR_NO_DEVICE
+
+
 def test_product_does_not_import_the_oracle():
     """The shipped package must not reference oracle/ (only tests, smoke and the bench baseline may)."""
     pkg_dir = os.path.join(ROOT, "tfhe-research_amd")
