@@ -154,9 +154,12 @@ struct DeviceWave {
 // where one 12-wave team per CU leaves LDS to spare and the barriers of a 768-thread workgroup are
 // dear (+5 % at cfg5).  One at N = 1024 (4 teams per CU would need 192 KiB with two) and at N = 512
 // (two fit, 139 KiB, but measured no gain at cfg3: 114.6 vs 116.1 ms per 4096 gates).
+#ifndef TFHE_EXB_N512
+#define TFHE_EXB_N512 1
+#endif
 template <int LOGN>
 struct ExchangeBuffersOf {
-  static constexpr int value = (LOGN >= 11) ? 2 : 1;
+  static constexpr int value = (LOGN >= 11) ? 2 : (LOGN == 9) ? TFHE_EXB_N512 : 1;
 };
 
 // (Two and four teams per workgroup -- one barrier sequence, one twiddle table, the second wave that asks for
