@@ -363,13 +363,22 @@ TFHE_HD void external_product_team_multi(const Ctx& c, const PbsParams& P, const
       constexpr int q = ci % ACCS, r0 = ((ci / ACCS) % PIECES) * CH, sp = ci / (ACCS * PIECES);
       constexpr int cur = ci % NB;
       if constexpr (ci + NB - 1 < CHUNKS) load_chunk(level, IntC<ci + NB - 1>{}, (ci + NB - 1) % NB);
-      if constexpr (q == 0) {
+      // (TFHE_PROBE_NO_EXCHANGE_READS: timing probe, WRONG BITS -- the digit spectra are not read back from LDS.)
+#ifndef TFHE_PROBE_NO_EXCHANGE_READS
+#define TFHE_PROBE_NO_EXCHANGE_READS 0
+#endif
+      if constexpr (q == 0 && !(TFHE_PROBE_NO_EXCHANGE_READS)) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
           const elem* spec = cl[s].scratch_of(sp);
 #pragma unroll
           for (int r = 0; r < CH; ++r) d[s][r] = spec[exchange_slot<LT, G>(lane, r0 + r)];
         }
+      } else if constexpr (q == 0 && ci == 0) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+          for (int r = 0; r < CH; ++r) d[s][r] = kbuf[0][r];
       }
       c.compiler_fence();  // keep the next chunk's loads above this chunk's arithmetic
 #pragma unroll
