@@ -294,6 +294,18 @@ blind_rotate_kernel(PbsParams P, const typename F::elem* __restrict__ tw,
     tvs[s] = tv + sample[s] * tv_stride;
   }
 
+  // (TFHE_STAGGER: experiment -- teams that are likely to share a CU start a fraction of a level apart, so that one team's
+  // multiply-accumulate (key fill) overlaps another's transforms (VALU); units of 64 cycles per phase step)
+#ifndef TFHE_STAGGER
+#define TFHE_STAGGER 0
+#endif
+#ifndef TFHE_STAGGER_SHIFT
+#define TFHE_STAGGER_SHIFT 8
+#endif
+  if (TFHE_STAGGER > 0) {
+    const unsigned phase = (blockIdx.x >> TFHE_STAGGER_SHIFT) & 3u;
+    for (unsigned i = 0; i < phase; ++i) __builtin_amdgcn_s_sleep(TFHE_STAGGER);
+  }
   blind_rotate_team_multi<F, LOGN, K, G, NS>(w, P, lwes, tvs, bsk);
 
   const int tid = w.tid();
