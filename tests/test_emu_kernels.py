@@ -402,7 +402,7 @@ def test_blind_rotate_and_extract_vs_oracle(emu, oracle, exchange_buffers, field
 
 
 @pytest.mark.parametrize("k,logn,n,pbs,log_p,g", [(1, 9, 5, (8, 2), 2, 1), (2, 9, 4, (4, 6), 2, 1), (1, 10, 3, (8, 4), 2, 1),
-                                                  (2, 11, 3, (8, 4), 4, 4)])
+                                                  (2, 11, 3, (8, 4), 4, 4), (1, 11, 3, (8, 3), 2, 4)])
 def test_two_samples_per_team_vs_oracle(emu, oracle, k, logn, n, pbs, log_p, g):
     """pbs_wave.h::blind_rotate_team_multi with NS = 2 (the complex transform's kernels at N = 512, k = 2 and N = 2048):
     a team rotates two samples at once -- one key fetch, one set of barriers, the inverse transforms in lockstep -- and

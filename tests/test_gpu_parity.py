@@ -15,6 +15,7 @@ SHAPES = [
     ("cfg5_small", 2, 11, 2, (8, 4), (4, 5), 4),
     ("k2_n1024", 2, 10, 3, (4, 7), (8, 3), 3),
     ("k1_n2048", 1, 11, 2, (16, 2), (2, 9), 2),
+    ("k1_n2048_b8", 1, 11, 3, (8, 3), (4, 5), 2),  # N = 2048 with k = 1 inside the complex transform's bound: 8-wave teams, two samples each
 ]
 
 
