@@ -532,12 +532,8 @@ def test_device_headers_under_address_and_ub_sanitizers():
     bsk_prepare / external product / blind rotation / keygen with ASan + UBSan (CPU only: the GPU
     pool has no sanitizer).  LDS is an exact-size heap buffer there, so a bad slot or twiddle index
     is an error, and so is signed overflow or an out-of-range shift."""
-    exe = os.path.join(EMU_DIR, "sanitize")
-    src = os.path.join(EMU_DIR, "sanitize_main.cpp")
-    deps = [src, os.path.join(EMU_DIR, "emu.cpp")] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    if not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps):
-        subprocess.run(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-fsanitize=address,undefined",  # add -g to localise a report
-                        "-fno-sanitize-recover=all", "-pthread", "-I", CSRC, src, "-o", exe], check=True)
+    import conftest
+    exe = conftest.sanitizer_binary() or conftest.sanitizer_binary()  # first call may only start the build; the second joins it
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
     res = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
