@@ -57,6 +57,7 @@ struct HostWave {
   const Elem* twiddles() const { return t_->tw.data(); }
   const Elem* twiddles_uniform() const { return t_->tw_natural.data(); }
   u32 uniform(u32 v) const { return v; }
+  void lds_add(u32* p, u32 v) const { *p += v; }
   void compiler_fence() const {}
 };
 

@@ -133,6 +133,14 @@ struct DeviceWave {
   __device__ __forceinline__ const Elem* twiddles() const { return tw_; }
   __device__ __forceinline__ const Elem* twiddles_uniform() const { return twg_; }
   __device__ __forceinline__ u32 uniform(u32 v) const { return __builtin_amdgcn_readfirstlane(v); }
+  // *p += v on an LDS word this lane owns: one ds_add_u32 (no return value) instead of a read, an add and a write
+#ifndef TFHE_LDS_ADD
+#define TFHE_LDS_ADD 1
+#endif
+  __device__ __forceinline__ void lds_add(u32* p, u32 v) const {
+    if (TFHE_LDS_ADD) (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    else *p += v;
+  }
   // compiler-only barrier: memory operations are not moved across it
   __device__ __forceinline__ void compiler_fence() const { asm volatile("" ::: "memory"); }
 };

@@ -511,7 +511,7 @@ TFHE_HD void blind_rotate_team_multi(const Ctx& c, const PbsParams& P, const u32
       return monomial_coeff<LOGN>(acc, j, a_tilde[s]) - acc[j];
     };
     // all rotated reads of acc happen before the first inverse transform: in-place update is safe
-    auto out = [&](int, int s, int j, u32 value) { c.acc(s)[j] += value; };
+    auto out = [&](int, int s, int j, u32 value) { c.lds_add(c.acc(s) + j, value); };
     external_product_team_multi<F, LOGN, K, G, 1, NS>(c, P, bsk + (size_t)i * ggsw_words, 0, src, out, [](int) {});
     // G > 1: the other waves of my group read what I just wrote (with two exchange buffers and one sample the
     // product already ended with a team barrier)
