@@ -71,18 +71,27 @@ def measure_hbm_copy_gbs(torch, dev, mib: int = 1024, reps: int = 10, ctx=None) 
 
 
 def kernel_source_hash() -> str:
-    """sha256 over the sources the device code is built from (csrc/*, include/tfhe_hip.h, the build recipe), first
-    16 hex digits: identifies the kernels a PMC record was measured on.  (Not the .so itself: hipcc output embeds
-    build paths, and the box that collects counters builds nothing -- it runs the library this tree built.)"""
+    """sha256 over the CODE of the sources the device library is built from (csrc/*, include/tfhe_hip.h, the build
+    recipe), first 16 hex digits: identifies the kernels a PMC record was measured on.  Comments and white space do not
+    count (a reworded comment must not invalidate a measurement; any token that reaches the compiler does).  (Not the .so
+    itself: hipcc output embeds build paths, and the box that collects counters builds nothing -- it runs the library
+    this tree built.)"""
     import hashlib
+    import re
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "tfhe-research_amd", "csrc")
     files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc))
     files += [os.path.join(ROOT, "include", "tfhe_hip.h"), os.path.join(ROOT, "tfhe-research_amd", "build.py")]
     for f in files:
-        h.update(os.path.basename(f).encode() + b"\0")
-        with open(f, "rb") as fh:
-            h.update(fh.read())
+        with open(f, "r", errors="replace") as fh:
+            text = fh.read()
+        if f.endswith(".py"):
+            text = re.sub(r"#[^\n]*", "", text)
+        else:
+            text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)   # block comments
+            text = re.sub(r"//[^\n]*", "", text)                # line comments (no string literal of these sources holds "//")
+        text = re.sub(r"\s+", " ", text).strip()
+        h.update(os.path.basename(f).encode() + b"\0" + text.encode() + b"\0")
     return h.hexdigest()[:16]
 
 

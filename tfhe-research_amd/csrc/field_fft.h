@@ -21,7 +21,10 @@
 // u = 2^-53; our twiddles are correctly rounded from long double, each component within u/2, |error| <= u / sqrt 2,
 // so eta <= 7.1 u = 7.9e-16 with room to spare; the forward transforms here use a six-FMA butterfly whose own
 // per-stage perturbation is 4.32 u, derived at FftField::butterfly_forward below; the inverse ones the textbook
-// sum / difference-times-twiddle form).  With x the folded digits (|x_j| <= sqrt 2 B), y the folded key half
+// sum / difference-times-twiddle form; the theorem's mechanism is an induction that needs nothing but a per-stage
+// perturbation bound: x~_k = A_k x~_(k-1) + f_k with ||f_k||_2 <= eps ||A_k x~_(k-1)||_2 and A_k / sqrt 2 unitary gives
+// ||x~_n - x_n||_2 <= n eps ||x_n||_2 (1 + O(n eps)), whatever the order of the operations inside a butterfly).
+// With x the folded digits (|x_j| <= sqrt 2 B), y the folded key half
 // (|y_j| <= sqrt 2 2^15), X, Y their unnormalised transforms (||X||_2 <= M |x|max, ||Y||_inf <= M |y|max),
 // R = (k+1) l rows accumulated in the transform domain, n = log2 M stages:
 //   forward errors   ||X~ - X||_2 <= n eta M |x|,  the same for Y (the prepared key)
