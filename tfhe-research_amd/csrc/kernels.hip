@@ -9,6 +9,7 @@
 #include <cstdlib>
 
 #include "launch.h"
+#include "pbs_split.h"
 
 namespace tfhe {
 namespace {
@@ -138,7 +139,7 @@ struct DeviceWave {
 #define TFHE_LDS_ADD 1
 #endif
   __device__ __forceinline__ void lds_add(u32* p, u32 v) const {
-    if (TFHE_LDS_ADD) (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    if (TFHE_LDS_ADD) (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else *p += v;
   }
   // compiler-only barrier: memory operations are not moved across it
@@ -326,6 +327,77 @@ blind_rotate_kernel(PbsParams P, const typename F::elem* __restrict__ tw,
       for (int r = 0; r < E; ++r) dst[r * T + tid] = w.acc(s)[r * T + tid];
     }
     if (lwe_extracted) sample_extract_team<LOGN, K, G>(w, lwe_extracted + sample[s] * ((size_t)K * N + 1), s);
+  }
+}
+
+// ------------------------------------------------------------------------------ EXPERIMENT: split-part team (pbs_split.h)
+#ifndef TFHE_SPLIT_N1024
+#define TFHE_SPLIT_N1024 0
+#endif
+// LDS: [ twiddles ][ group g = 2 c + q: exchange buffer N x 8 B | accumulator polynomial (c, sample q) N x 4 B ], g < 2 (K + 1)
+template <class F, int LOGN, int K>
+struct SplitCfg {
+  static constexpr int N = 1 << LOGN;
+  static constexpr int kGroups = 2 * (K + 1);
+  static constexpr int kThreads = kGroups * 64;
+  static constexpr unsigned kGroupLds = (unsigned)N * 8u + (unsigned)N * 4u;
+  static constexpr size_t kTwBytes = (size_t)staged_twiddle_words<F, LOGN>() * sizeof(typename F::elem);
+  static constexpr size_t kLds = kTwBytes + (size_t)kGroups * kGroupLds;
+};
+
+template <class F, int LOGN, int K>
+__global__ void __launch_bounds__((SplitCfg<F, LOGN, K>::kThreads), 2)
+blind_rotate_split_kernel(PbsParams P, const typename F::elem* __restrict__ tw, const u32* __restrict__ lwe_in, size_t batch,
+                          const u32* __restrict__ tv, size_t tv_stride, const typename F::elem* __restrict__ bsk,
+                          u32* __restrict__ glwe_out, u32* __restrict__ lwe_extracted) {
+  typedef typename F::elem elem;
+  using C = SplitCfg<F, LOGN, K>;
+  constexpr int N = C::N;
+  constexpr int E = NttShape<LOGN, 1>::kE;
+  elem* twl = reinterpret_cast<elem*>(g_smem);
+  ntt_stage_twiddles<LOGN - F::kLogShrink, 1, elem, staged_twiddle_words<F, LOGN>()>(twl, tw, (int)threadIdx.x, (int)blockDim.x);
+  __syncthreads();
+  DeviceWave<elem, 1, 1> w;
+  w.group_ = (int)(threadIdx.x / 64u);
+  w.group_stride_ = C::kGroupLds;
+  w.buffer_bytes_ = (unsigned)N * 8u;
+  w.team_base_ = g_smem + C::kTwBytes;
+  w.tw_ = twl;
+  w.twg_ = tw;
+  w.scratch_ = reinterpret_cast<elem*>(w.team_base_ + (size_t)w.group_ * C::kGroupLds);
+  // acc(s): accumulator polynomial (group >> 1) of sample s lives in the region of group 2 (group >> 1) + s
+  w.acc_ = reinterpret_cast<u32*>(w.team_base_ + (size_t)(w.group_ & ~1) * C::kGroupLds + (size_t)N * 8);
+  w.acc_words_ = C::kGroupLds / 4u;
+  size_t sample[2];
+  const u32* lwes[2];
+  const u32* tvs[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const size_t idx = (size_t)blockIdx.x * 2 + s;
+    sample[s] = idx < batch ? idx : batch - 1;
+    lwes[s] = lwe_in + sample[s] * (P.n + 1);
+    tvs[s] = tv + sample[s] * tv_stride;
+  }
+  blind_rotate_team_split<F, LOGN, K>(w, P, lwes, tvs, bsk);
+  const int me = w.group_ >> 1, mine = w.group_ & 1, tid = w.tid();
+  if ((size_t)blockIdx.x * 2 + mine >= batch) return;  // the duplicate of an odd batch's last sample
+  const u32* acc = w.acc(mine);
+  if (glwe_out) {
+    u32* dst = glwe_out + (sample[mine] * (size_t)(K + 1) + me) * N;
+#pragma unroll
+    for (int r = 0; r < E; ++r) dst[r * 64 + tid] = acc[r * 64 + tid];
+  }
+  if (lwe_extracted) {  // sample_extract at index 0 (bootstrapping.rs:122-156)
+    u32* out = lwe_extracted + sample[mine] * ((size_t)K * N + 1);
+    if (me < K) {
+#pragma unroll
+      for (int r = 0; r < E; ++r) {
+        const int x = r * 64 + tid;
+        out[me * N + x] = (x == 0) ? acc[0] : (0u - acc[N - x]);
+      }
+    } else if (tid == 0) {
+      out[K * N] = acc[0];
+    }
   }
 }
 
@@ -805,6 +877,24 @@ hipError_t launch_blind_rotate(hipStream_t s, const PbsParams& P, const void* tw
     using C = TeamCfg<F, LOGN, K>;
     auto tw = static_cast<const typename F::elem*>(tw_v);
     auto bsk = static_cast<const typename F::elem*>(bsk_v);
+    if constexpr (TFHE_SPLIT_N1024 && F::kLogShrink == 1 && LOGN == 10) {  // EXPERIMENT: pbs_split.h
+      using SC = SplitCfg<F, LOGN, K>;
+      auto skern = blind_rotate_split_kernel<F, LOGN, K>;
+      static std::atomic<unsigned long long> split_lds_done{0};
+      hipError_t se = allow_lds(skern, SC::kLds, split_lds_done);
+      if (se != hipSuccess) return se;
+      const size_t schunk = blind_rotate_chunk<F>();
+      for (size_t off = 0; off < batch; off += schunk) {
+        const size_t here = batch - off < schunk ? batch - off : schunk;
+        hipLaunchKernelGGL(skern, dim3((unsigned)((here + 1) / 2)), dim3(SC::kThreads), SC::kLds, s, P, tw,
+                           lwe_in + off * ((size_t)P.n + 1), here, tv + off * tv_stride, tv_stride, bsk,
+                           glwe_out ? glwe_out + off * (size_t)(K + 1) * SC::N : nullptr,
+                           lwe_extracted ? lwe_extracted + off * ((size_t)K * SC::N + 1) : nullptr);
+        se = hipGetLastError();
+        if (se != hipSuccess) return se;
+      }
+      return hipSuccess;
+    }
     auto kern = blind_rotate_kernel<F, LOGN, K>;
     static std::atomic<unsigned long long> lds_done{0};
     hipError_t e = allow_lds(kern, C::kLds, lds_done);
