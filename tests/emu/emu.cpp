@@ -21,6 +21,7 @@ using namespace tfhe;
 namespace {
 
 int g_exchange_buffers = 1;  // exchange buffers per group (kernels.hip::ExchangeBuffersOf)
+int g_segments = 1;  // launches a blind rotation is cut into (kernels.hip::blind_rotate_segments): resumes from parked accumulators
 int g_samples_per_team = 1;  // samples a team rotates at once (kernels.hip::SamplesPerTeam): each needs a buffer and an accumulator
 
 template <class Elem>
@@ -158,6 +159,7 @@ void blind_rotate(const PbsParams& P, size_t batch, const u32* lwe, const u32* t
   constexpr int N = 1 << LOGN;
   constexpr int E = NttShape<LOGN, G>::kE;
   constexpr int T = NttShape<LOGN, G>::kThreads;
+  std::vector<u32> state((size_t)NS * (K + 1) * N);
   if constexpr (!shape_ok<F, LOGN, G>()) std::abort();
   else
   run_team<F>(LOGN, K + 1, G, [&](const HostWave<elem>& w) {
@@ -171,7 +173,20 @@ void blind_rotate(const PbsParams& P, size_t batch, const u32* lwe, const u32* t
         lwes[s] = lwe + idx[s] * (P.n + 1);
         tvs[s] = tv + idx[s] * tv_stride;
       }
-      blind_rotate_team_multi<F, LOGN, K, G, NS>(w, P, lwes, tvs, bsk);
+      // the rotation in g_segments pieces, the accumulators parked in `state` in between -- as blind_rotate_kernel does
+      const u32 per = (P.n + g_segments - 1) / g_segments;
+      const u32* resume[NS];
+      for (int s = 0; s < NS; ++s) resume[s] = state.data() + (size_t)s * (K + 1) * N;
+      for (u32 i0 = 0; i0 < P.n; i0 += per) {
+        const u32 i1 = i0 + per < P.n ? i0 + per : P.n;
+        blind_rotate_team_multi<F, LOGN, K, G, NS>(w, P, lwes, tvs, bsk, i0, i1, resume);
+        if (i1 < P.n) {
+          for (int s = 0; s < NS; ++s)
+            for (int r = 0; r < E; ++r)
+              state[((size_t)s * (K + 1) + w.group()) * N + r * T + w.tid()] = w.acc(s)[r * T + w.tid()];
+          w.team_sync();
+        }
+      }
       for (int s = 0; s < NS && b0 + s < batch; ++s) {
         const size_t b = idx[s];
         if (out_glwe)
@@ -281,6 +296,7 @@ extern "C" {
 void emu_set_aligned(int aligned) { g_aligned = aligned != 0; }
 void emu_set_exchange_buffers(int n) { g_exchange_buffers = n == 2 ? 2 : 1; }
 void emu_set_samples_per_team(int n) { g_samples_per_team = n == 2 ? 2 : 1; }
+void emu_set_segments(int n) { g_segments = n > 1 ? n : 1; }
 int emu_field_parts(int field) { return (field == 1 || field == 4) ? 1 : 2; }
 // 1 if the emulator can run `field` at ring degree 2^logn with g waves per polynomial
 int emu_field_shape_ok(int field, int logn, int g) {

@@ -432,6 +432,33 @@ def test_two_samples_per_team_vs_oracle(emu, oracle, k, logn, n, pbs, log_p, g):
         assert np.array_equal(ext[b], tr["extracted_lwe"]), f"sample {b}"
 
 
+@pytest.mark.parametrize("field,k,logn,n,pbs,log_p,g,ns,segments", [(FFT, 2, 9, 5, (4, 6), 2, 1, 2, 2), (FFT, 1, 10, 5, (8, 4), 2, 1, 1, 3),
+                                                                     (FFT, 2, 11, 3, (8, 4), 4, 4, 2, 3), (FP, 1, 9, 4, (8, 2), 2, 1, 1, 4)])
+def test_segmented_blind_rotation_vs_oracle(emu, oracle, field, k, logn, n, pbs, log_p, g, ns, segments):
+    """pbs_wave.h::blind_rotate_team_multi over iteration ranges: a rotation cut into several launches (kernels.hip blocks
+    the key for the caches that way) parks the accumulators in global memory and resumes from them -- the same words as
+    the uninterrupted rotation, with one and with two samples per team, segments that do not divide n, odd batch"""
+    params = oracle.Params(k, logn, n, oracle.Decomposer(*pbs), log_p=log_p)
+    batch = 3
+    lwe, bsk, ksk, tv = oracle.synthetic_inputs(params, batch, cfg_index=90 + logn)
+    spec = prepared(emu, field, params, bsk, g)
+    glwe = np.zeros((batch, k + 1, params.N), dtype=np.uint32)
+    ext = np.zeros((batch, params.big_n + 1), dtype=np.uint32)
+    emu.emu_set_samples_per_team(ns)
+    emu.emu_set_segments(segments)
+    try:
+        rc = emu.emu_blind_rotate(field, g, n, k, logn, log_p, 1, pbs[0], pbs[1], C.c_size_t(batch), p32(lwe), p32(tv),
+                                  C.c_size_t(0), p64(spec), p32(glwe), p32(ext))
+    finally:
+        emu.emu_set_samples_per_team(1)
+        emu.emu_set_segments(1)
+    assert rc == 0
+    for b in range(batch):
+        _, tr = oracle.bootstrap(params, lwe[b], bsk, ksk, tv, trace=True)
+        assert np.array_equal(glwe[b], tr["acc_final"]), f"sample {b}"
+        assert np.array_equal(ext[b], tr["extracted_lwe"]), f"sample {b}"
+
+
 @pytest.mark.parametrize("k,logn,n,pbs,log_p,g,exb", CASES_P49)
 def test_fp49_field_more_shapes(emu, oracle, k, logn, n, pbs, log_p, g, exb):
     """external product and blind rotation + sample extract in the 49-bit single-spectrum field"""

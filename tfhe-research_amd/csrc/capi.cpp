@@ -134,9 +134,13 @@ using tfhe::host::io_words;
 // notes/BMMP Bootstrapping.md with a BMMP key
 hipError_t enqueue_blind_rotate(tfhe_context* ctx, const u32* lwe_in, size_t batch, const u32* tv,
                                 size_t tv_count, u32* glwe_out, u32* lwe_extracted) {
-  auto fn = ctx->bmmp ? launch::blind_rotate_bmmp : launch::blind_rotate;
-  return fn(ctx->stream, ctx->field, ctx->pbs, ctx->d_tw, lwe_in, batch, tv, tv_count == 1 ? 0 : ctx->N,
-            ctx->d_bsk, glwe_out, lwe_extracted);
+  if (ctx->bmmp)
+    return launch::blind_rotate_bmmp(ctx->stream, ctx->field, ctx->pbs, ctx->d_tw, lwe_in, batch, tv,
+                                     tv_count == 1 ? 0 : ctx->N, ctx->d_bsk, glwe_out, lwe_extracted);
+  // accumulators between the launches of a segmented rotation: the caller's output, or the workspace (sized by reserve)
+  u32* state = glwe_out ? glwe_out : (batch <= ctx->ws_batch ? ctx->d_glwe_c : nullptr);
+  return launch::blind_rotate(ctx->stream, ctx->field, ctx->pbs, ctx->d_tw, lwe_in, batch, tv, tv_count == 1 ? 0 : ctx->N,
+                              ctx->d_bsk, glwe_out, lwe_extracted, state);
 }
 
 // d_lwe_big: [batch][k*N+1] scratch of the reference order (unused when the key switch comes first)

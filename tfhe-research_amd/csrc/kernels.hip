@@ -282,7 +282,8 @@ __global__ void __launch_bounds__((TeamCfg<F, LOGN, K>::kThreads),
 blind_rotate_kernel(PbsParams P, const typename F::elem* __restrict__ tw,
                     const u32* __restrict__ lwe_in, size_t batch, const u32* __restrict__ tv,
                     size_t tv_stride, const typename F::elem* __restrict__ bsk,
-                    u32* __restrict__ glwe_out, u32* __restrict__ lwe_extracted) {
+                    u32* __restrict__ glwe_out, u32* __restrict__ lwe_extracted,
+                    u32 i_begin, u32 i_end, u32* glwe_state /* [batch][K+1][N]: accumulators between segments */) {
   using C = TeamCfg<F, LOGN, K>;
   constexpr int N = C::N;
   constexpr int G = C::G;
@@ -315,9 +316,22 @@ blind_rotate_kernel(PbsParams P, const typename F::elem* __restrict__ tw,
     const unsigned phase = (blockIdx.x >> TFHE_STAGGER_SHIFT) & 3u;
     for (unsigned i = 0; i < phase; ++i) __builtin_amdgcn_s_sleep(TFHE_STAGGER);
   }
-  blind_rotate_team_multi<F, LOGN, K, G, NS>(w, P, lwes, tvs, bsk);
+  const u32* resume[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) resume[s] = glwe_state + sample[s] * (size_t)(K + 1) * N;
+  blind_rotate_team_multi<F, LOGN, K, G, NS>(w, P, lwes, tvs, bsk, i_begin, i_end, resume);
 
   const int tid = w.tid();
+  if (i_end < P.n) {  // not the last segment: park the accumulators
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      if ((size_t)blockIdx.x * NS + s >= batch) break;
+      u32* dst = glwe_state + (sample[s] * (size_t)(K + 1) + w.group()) * N;
+#pragma unroll
+      for (int r = 0; r < E; ++r) dst[r * T + tid] = w.acc(s)[r * T + tid];
+    }
+    return;
+  }
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     if ((size_t)blockIdx.x * NS + s >= batch) break;  // the duplicate of an odd batch's last sample
@@ -867,10 +881,36 @@ inline size_t blind_rotate_chunk() {
   return F::kLogShrink ? (size_t)4096 : ((size_t)1 << 20);
 }
 
+// Launches per blind rotation.  A launch of 4,096 samples sweeps the WHOLE prepared key once per round of resident teams,
+// and teams that drift apart -- or that belong to different rounds -- sit at different iterations: when the key does not
+// fit the 256 MiB Infinity Cache (the reference's default parameters: 319 MB; N = 2048, k = 2: 743 MB) a good part of it
+// streams from HBM again and again (PMC, cfg3: 258 GB per launch = 4 TB/s).  Cutting the n iterations into segments
+// -- every launch walks only key rows [i0, i1) and parks the accumulators in global memory -- blocks the key for the
+// caches: measured (profiles/r03_kernel_ab.txt) cfg3 62.2 k -> 71.2 k PBS/s from 32 segments on (slices of <= 10 MB: the
+// L2s hold them), cfg5 18.8 k -> 20.95 k from 4 on (slices of <= 186 MB: the Infinity Cache holds them; no more from
+// smaller ones), cfg2 and cfg1 (124 and 33 MB: they fit as they are) nothing or a loss.  Hence: one launch if the key
+// fits the Infinity Cache with room to spare, otherwise slices of 8 MiB at N = 512 and of 128 MiB above.
+// TFHE_BR_SEGMENTS overrides the count.
+inline u32 blind_rotate_segments(u32 n, size_t key_bytes, u32 log_n) {
+  static const u32 env_segments = [] {
+    const char* env = std::getenv("TFHE_BR_SEGMENTS");
+    const long v = env ? std::atol(env) : 0;
+    return v > 0 ? (u32)v : 0u;
+  }();
+  u32 segments = env_segments;
+  if (segments == 0) {
+    const size_t fits = (size_t)224 << 20;
+    const size_t slice = (size_t)(log_n <= 9 ? 8 : 128) << 20;
+    segments = key_bytes <= fits ? 1u : (u32)((key_bytes + slice - 1) / slice);
+  }
+  if (segments > n) segments = n;
+  return segments ? segments : 1u;
+}
+
 template <class F, int LOGN, int K>
 hipError_t launch_blind_rotate(hipStream_t s, const PbsParams& P, const void* tw_v, const u32* lwe_in,
                                size_t batch, const u32* tv, size_t tv_stride, const void* bsk_v,
-                               u32* glwe_out, u32* lwe_extracted) {
+                               u32* glwe_out, u32* lwe_extracted, u32* state) {
   if constexpr (!field_shape_ok<F, LOGN>()) {
     return hipErrorInvalidValue;  // the context never picks such a field (capi.cpp)
   } else {
@@ -906,14 +946,23 @@ hipError_t launch_blind_rotate(hipStream_t s, const PbsParams& P, const void* tw
     // the complex-FFT kernel, which needs 13 TB/s of key, ran 75.0 k PBS/s that way against 108.9 k at 4,096
     // (profiles/r02_f_*).  Launches on one stream run back to back.
     const size_t chunk = blind_rotate_chunk<F>();
+    // ... and a launch may cover only a SEGMENT of the n CMUX iterations (blind_rotate_segments): the teams of a
+    // launch start a segment together, which bounds how far they drift apart over a long rotation
+    const size_t key_bytes = (size_t)P.n * (K + 1) * P.levels * (K + 1) * F::kParts * C::N * 8;
+    const u32 segments = state ? blind_rotate_segments(P.n, key_bytes, (u32)LOGN) : 1u;
+    const u32 per = (P.n + segments - 1) / segments;
     for (size_t off = 0; off < batch; off += chunk) {
       const size_t here = batch - off < chunk ? batch - off : chunk;
-      hipLaunchKernelGGL(kern, dim3((unsigned)((here + C::S - 1) / C::S)), dim3(C::kThreads), C::kLds, s, P, tw,
-                         lwe_in + off * ((size_t)P.n + 1), here, tv + off * tv_stride, tv_stride, bsk,
-                         glwe_out ? glwe_out + off * (size_t)(K + 1) * C::N : nullptr,
-                         lwe_extracted ? lwe_extracted + off * ((size_t)K * C::N + 1) : nullptr);
-      e = hipGetLastError();
-      if (e != hipSuccess) return e;
+      for (u32 i0 = 0; i0 < P.n; i0 += per) {
+        const u32 i1 = i0 + per < P.n ? i0 + per : P.n;
+        hipLaunchKernelGGL(kern, dim3((unsigned)((here + C::S - 1) / C::S)), dim3(C::kThreads), C::kLds, s, P, tw,
+                           lwe_in + off * ((size_t)P.n + 1), here, tv + off * tv_stride, tv_stride, bsk,
+                           glwe_out ? glwe_out + off * (size_t)(K + 1) * C::N : nullptr,
+                           lwe_extracted ? lwe_extracted + off * ((size_t)K * C::N + 1) : nullptr, i0, i1,
+                           state ? state + off * (size_t)(K + 1) * C::N : nullptr);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+      }
     }
     return hipSuccess;
   }
@@ -1146,10 +1195,10 @@ hipError_t bsk_prepare(hipStream_t s, int field, u32 log_n, const void* tw, cons
 
 hipError_t blind_rotate(hipStream_t s, int field, const PbsParams& P, const void* tw,
                         const u32* lwe_in, size_t batch, const u32* tv, size_t tv_stride,
-                        const void* bsk, u32* glwe_out, u32* lwe_extracted) {
+                        const void* bsk, u32* glwe_out, u32* lwe_extracted, u32* state) {
   TFHE_DISPATCH_FIELD(field, TFHE_DISPATCH_LOGN_K(P.log_n, P.k,
                       (launch_blind_rotate<FF, LL, KK>(s, P, tw, lwe_in, batch, tv, tv_stride, bsk,
-                                                       glwe_out, lwe_extracted))));
+                                                       glwe_out, lwe_extracted, state))));
 }
 
 hipError_t blind_rotate_bmmp(hipStream_t s, int field, const PbsParams& P, const void* tw,

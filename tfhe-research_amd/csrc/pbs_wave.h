@@ -466,16 +466,31 @@ TFHE_HD void external_product_team(const Ctx& c, const PbsParams& P, const typen
 // NS = 1 is the plain one-sample-per-team form; with NS = 2 every CMUX iteration multiplies both samples'
 // rotated differences with GGSW_i in one pass (external_product_team_multi).
 // ---------------------------------------------------------------------------------------------
+// A blind rotation may be cut into SEGMENTS of CMUX iterations [i_begin, i_end), one launch each: a segment that does not
+// start at 0 resumes from the GLWE accumulators the previous one left in global memory (resume[s]: [K+1][N] of sample
+// s), and the caller stores c.acc(s) again if i_end < n.  (Teams of one launch start a segment together, so a long
+// rotation's drift -- and with it the span of the key the L2s have to hold -- is bounded by the segment; see
+// kernels.hip::blind_rotate_segments.)
 template <class F, int LOGN, int K, int G, int NS, class Ctx>
 TFHE_HD void blind_rotate_team_multi(const Ctx& c, const PbsParams& P, const u32* const* lwe /* NS x (n+1) */,
                                      const u32* const* tv /* NS x N, un-encoded */,
-                                     const typename F::elem* bsk /* prepared */) {
+                                     const typename F::elem* bsk /* prepared */, u32 i_begin, u32 i_end,
+                                     const u32* const* resume /* NS x [K+1][N], read if i_begin > 0 */) {
   constexpr int E = NttShape<LOGN, G>::kE;
   constexpr int T = NttShape<LOGN, G>::kThreads;
   constexpr int N = 1 << LOGN;
   const int lane = c.tid();
   const int me = c.group();
 
+  if (i_begin > 0) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      u32* acc = c.acc(s);
+      const u32* from = resume[s] + (size_t)me * N;
+#pragma unroll
+      for (int r = 0; r < E; ++r) acc[r * T + lane] = from[r * T + lane];
+    }
+  } else {
   // acc = X^{-b~} * (0, ..., 0, tv << tv_shift): only the body polynomial (wave K) is non-zero
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
@@ -495,11 +510,12 @@ TFHE_HD void blind_rotate_team_multi(const Ctx& c, const PbsParams& P, const u32
       acc[j] = val;
     }
   }
+  }
   c.poly_sync();
 
   const size_t ggsw_words = (size_t)(K + 1) * P.levels * (K + 1) * F::kParts * (N >> F::kLogShrink);  // elements
 #pragma unroll 1
-  for (u32 i = 0; i < P.n; ++i) {
+  for (u32 i = i_begin; i < i_end; ++i) {
     u32 a_tilde[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) a_tilde[s] = c.uniform(switch_modulus_2n(lwe[s][i], LOGN));
@@ -517,6 +533,12 @@ TFHE_HD void blind_rotate_team_multi(const Ctx& c, const PbsParams& P, const u32
     // product already ended with a team barrier)
     if (NS > 1 || c.exchange_buffers() != 2) c.poly_sync();
   }
+}
+
+template <class F, int LOGN, int K, int G, int NS, class Ctx>
+TFHE_HD void blind_rotate_team_multi(const Ctx& c, const PbsParams& P, const u32* const* lwe, const u32* const* tv,
+                                     const typename F::elem* bsk) {
+  blind_rotate_team_multi<F, LOGN, K, G, NS>(c, P, lwe, tv, bsk, 0u, P.n, nullptr);
 }
 
 template <class F, int LOGN, int K, int G, class Ctx>
