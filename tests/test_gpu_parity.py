@@ -586,18 +586,25 @@ def test_batch_edge_cases(oracle, contexts, name):
     assert e.value.status == 5
 
 
-@pytest.mark.parametrize("chunk", ["3", "2", "5"])
-def test_short_launches_with_two_samples_per_team(chunk):
-    """kernels.hip::launch_blind_rotate cuts a batch into launches of blind_rotate_chunk() samples (4,096 for fp64-fft);
-    TFHE_BR_CHUNK overrides it.  With launches of 3, 2 and 5 samples a batch of 8 exercises the launch offsets of inputs,
-    per-sample test vectors and both outputs, and -- at the shapes whose teams rotate two samples -- a last team that is
-    one sample short in every odd launch.  Three shapes against the oracle, in a child process (the variable is read once)."""
+@pytest.mark.parametrize("chunk,segments", [("3", None), ("2", None), ("5", None), ("3", "2"), ("8", "3"), ("5", "4")])
+def test_short_launches_with_two_samples_per_team(chunk, segments):
+    """kernels.hip::launch_blind_rotate cuts a batch into launches of blind_rotate_chunk() samples and the n CMUX
+    iterations into blind_rotate_segments() launches whose accumulators wait in global memory in between; TFHE_BR_CHUNK
+    and TFHE_BR_SEGMENTS override the two.  With launches of 3, 2 and 5 samples a batch of 8 exercises the launch offsets
+    of inputs, per-sample test vectors, parked accumulators and both outputs, and -- at the shapes whose teams rotate two
+    samples -- a last team that is one sample short in every odd launch; with 2, 3 and 4 segments (n = 4, 2, 3: more
+    segments than iterations are clamped) every launch but the first resumes.  Three shapes against the oracle, in a child
+    process (the variables are read once)."""
     import subprocess
     import sys
     import os
     here = os.path.dirname(os.path.abspath(__file__))
-    run = subprocess.run([sys.executable, os.path.join(here, "br_chunk_probe.py")], env=dict(os.environ, TFHE_BR_CHUNK=chunk),
-                         capture_output=True, text=True, timeout=600)
+    env = dict(os.environ, TFHE_BR_CHUNK=chunk)
+    env.pop("TFHE_BR_SEGMENTS", None)
+    if segments:
+        env["TFHE_BR_SEGMENTS"] = segments
+    run = subprocess.run([sys.executable, os.path.join(here, "br_chunk_probe.py")], env=env, capture_output=True, text=True,
+                         timeout=600)
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
     assert "short launches parity True" in run.stdout
 

@@ -867,31 +867,40 @@ hipError_t allow_lds(Kern kern, size_t bytes, std::atomic<unsigned long long>& d
   return e;
 }
 
-// samples per blind-rotation launch: 4,096 for the complex transform, whose kernel lives on an L2-hot key; the
-// prime-field kernels are VALU bound and lose 2.5 % to the launch boundaries (cfg3, 65,536 gates: 48.8 k against
-// 49.9 k gates/s), so they only split beyond 2^20 (the grid is a 32-bit number).  TFHE_BR_CHUNK overrides both.
+// Samples per blind-rotation launch.  The complex transform's kernel lives on an L2-hot key: 4,096 per launch when the
+// launch walks the whole key (in ONE launch of 131,072 the dispatcher refills finished teams one by one, every iteration of
+// the key is in use somewhere and it streams from the Infinity Cache: 75 k against 109 k PBS/s, round 2) -- but when the
+// rotation is cut into segments whose key slice the L2s hold whatever the teams' spread (blind_rotate_segments), LONG
+// launches win: fewer launch tails.  cfg4's share of 131,072: 118.3 k PBS/s in launches of 4,096, 128.9 k in one launch of
+// 64 segments; the 65,536-gate stream at the reference's defaults: 71.3 k -> 75.6 k gates/s (profiles/r03_kernel_ab.txt).
+// The prime-field kernels are VALU bound and lose 2.5 % to launch boundaries, so they only split beyond 2^20 (the grid is a
+// 32-bit number).  TFHE_BR_CHUNK overrides.
+constexpr size_t kLongBatch = 16384;  // from here on a batch goes out in long, segmented launches
 template <class F>
-inline size_t blind_rotate_chunk() {
+inline size_t blind_rotate_chunk(size_t batch, bool can_segment, u32 log_n) {
   static const size_t env_chunk = [] {
     const char* env = std::getenv("TFHE_BR_CHUNK");
     const long v = env ? std::atol(env) : 0;
     return v > 0 ? (size_t)v : (size_t)0;
   }();
   if (env_chunk) return env_chunk;
-  return F::kLogShrink ? (size_t)4096 : ((size_t)1 << 20);
+  if (!F::kLogShrink) return (size_t)1 << 20;
+  if (can_segment && batch >= kLongBatch) return log_n >= 11 ? (size_t)16384 : (size_t)131072;
+  return 4096;
 }
 
-// Launches per blind rotation.  A launch of 4,096 samples sweeps the WHOLE prepared key once per round of resident teams,
-// and teams that drift apart -- or that belong to different rounds -- sit at different iterations: when the key does not
-// fit the 256 MiB Infinity Cache (the reference's default parameters: 319 MB; N = 2048, k = 2: 743 MB) a good part of it
+// Launches per blind rotation.  A launch that walks the WHOLE prepared key sweeps it once per round of resident teams, and
+// teams that drift apart -- or that belong to different rounds -- sit at different iterations: when the key does not fit
+// the 256 MiB Infinity Cache (the reference's default parameters: 319 MB; N = 2048, k = 2: 743 MB) a good part of it
 // streams from HBM again and again (PMC, cfg3: 258 GB per launch = 4 TB/s).  Cutting the n iterations into segments
 // -- every launch walks only key rows [i0, i1) and parks the accumulators in global memory -- blocks the key for the
-// caches: measured (profiles/r03_kernel_ab.txt) cfg3 62.2 k -> 71.2 k PBS/s from 32 segments on (slices of <= 10 MB: the
-// L2s hold them), cfg5 18.8 k -> 20.95 k from 4 on (slices of <= 186 MB: the Infinity Cache holds them; no more from
-// smaller ones), cfg2 and cfg1 (124 and 33 MB: they fit as they are) nothing or a loss.  Hence: one launch if the key
-// fits the Infinity Cache with room to spare, otherwise slices of 8 MiB at N = 512 and of 128 MiB above.
-// TFHE_BR_SEGMENTS overrides the count.
-inline u32 blind_rotate_segments(u32 n, size_t key_bytes, u32 log_n) {
+// caches.  Measured (profiles/r03_kernel_ab.txt), batch 4,096: cfg3 62.2 k -> 71.2 k PBS/s from 32 segments on (slices of
+// <= 10 MB: the L2s hold them), cfg5 18.8 k -> 20.95 k from 4 on (slices of <= 186 MB: the Infinity Cache holds them; no more
+// from smaller ones), cfg2 and cfg1 (124 and 33 MB: they fit as they are) nothing or a loss.  Long launches (blind_rotate_chunk)
+// want L2-sized slices whatever the key's size: best at 1.9-2.7 MB.  Hence: slices of 128 MiB at N = 2048; below, slices of
+// 2 MiB in long launches, and of 8 MiB in launches of 4,096 if the key does not fit the Infinity Cache with room to spare.
+// At least 4 iterations per segment.  TFHE_BR_SEGMENTS overrides the count.
+inline u32 blind_rotate_segments(u32 n, size_t key_bytes, u32 log_n, bool long_launch) {
   static const u32 env_segments = [] {
     const char* env = std::getenv("TFHE_BR_SEGMENTS");
     const long v = env ? std::atol(env) : 0;
@@ -899,9 +908,13 @@ inline u32 blind_rotate_segments(u32 n, size_t key_bytes, u32 log_n) {
   }();
   u32 segments = env_segments;
   if (segments == 0) {
-    const size_t fits = (size_t)224 << 20;
-    const size_t slice = (size_t)(log_n <= 9 ? 8 : 128) << 20;
-    segments = key_bytes <= fits ? 1u : (u32)((key_bytes + slice - 1) / slice);
+    const bool fits = key_bytes <= ((size_t)224 << 20);
+    size_t slice = 0;
+    if (log_n >= 11) slice = fits ? 0 : (size_t)128 << 20;
+    else if (long_launch) slice = (size_t)2 << 20;
+    else slice = fits ? 0 : (size_t)8 << 20;
+    segments = slice ? (u32)((key_bytes + slice - 1) / slice) : 1u;
+    if (segments > n / 4) segments = n / 4;
   }
   if (segments > n) segments = n;
   return segments ? segments : 1u;
@@ -923,7 +936,7 @@ hipError_t launch_blind_rotate(hipStream_t s, const PbsParams& P, const void* tw
       static std::atomic<unsigned long long> split_lds_done{0};
       hipError_t se = allow_lds(skern, SC::kLds, split_lds_done);
       if (se != hipSuccess) return se;
-      const size_t schunk = blind_rotate_chunk<F>();
+      const size_t schunk = blind_rotate_chunk<F>(batch, false, (u32)LOGN);
       for (size_t off = 0; off < batch; off += schunk) {
         const size_t here = batch - off < schunk ? batch - off : schunk;
         hipLaunchKernelGGL(skern, dim3((unsigned)((here + 1) / 2)), dim3(SC::kThreads), SC::kLds, s, P, tw,
@@ -945,11 +958,11 @@ hipError_t launch_blind_rotate(hipStream_t s, const PbsParams& P, const void* tw
     // iteration of the key is in use somewhere and the 124 MB key streams from the Infinity Cache instead:
     // the complex-FFT kernel, which needs 13 TB/s of key, ran 75.0 k PBS/s that way against 108.9 k at 4,096
     // (profiles/r02_f_*).  Launches on one stream run back to back.
-    const size_t chunk = blind_rotate_chunk<F>();
-    // ... and a launch may cover only a SEGMENT of the n CMUX iterations (blind_rotate_segments): the teams of a
-    // launch start a segment together, which bounds how far they drift apart over a long rotation
+    const size_t chunk = blind_rotate_chunk<F>(batch, state != nullptr, (u32)LOGN);
+    // ... and a launch may cover only a SEGMENT of the n CMUX iterations (blind_rotate_segments): the key slice it walks
+    // stays in the caches whatever the spread of its teams
     const size_t key_bytes = (size_t)P.n * (K + 1) * P.levels * (K + 1) * F::kParts * C::N * 8;
-    const u32 segments = state ? blind_rotate_segments(P.n, key_bytes, (u32)LOGN) : 1u;
+    const u32 segments = state ? blind_rotate_segments(P.n, key_bytes, (u32)LOGN, chunk >= kLongBatch && batch >= kLongBatch) : 1u;
     const u32 per = (P.n + segments - 1) / segments;
     for (size_t off = 0; off < batch; off += chunk) {
       const size_t here = batch - off < chunk ? batch - off : chunk;
