@@ -586,23 +586,26 @@ def test_batch_edge_cases(oracle, contexts, name):
     assert e.value.status == 5
 
 
-@pytest.mark.parametrize("chunk,segments", [("3", None), ("2", None), ("5", None), ("3", "2"), ("8", "3"), ("5", "4")])
-def test_short_launches_with_two_samples_per_team(chunk, segments):
-    """kernels.hip::launch_blind_rotate cuts a batch into launches of blind_rotate_chunk() samples and the n CMUX
-    iterations into blind_rotate_segments() launches whose accumulators wait in global memory in between; TFHE_BR_CHUNK
-    and TFHE_BR_SEGMENTS override the two.  With launches of 3, 2 and 5 samples a batch of 8 exercises the launch offsets
-    of inputs, per-sample test vectors, parked accumulators and both outputs, and -- at the shapes whose teams rotate two
-    samples -- a last team that is one sample short in every odd launch; with 2, 3 and 4 segments (n = 4, 2, 3: more
-    segments than iterations are clamped) every launch but the first resumes.  Three shapes against the oracle, in a child
-    process (the variables are read once)."""
+@pytest.mark.parametrize("chunk,segments,streams", [("3", None, None), ("2", None, None), ("5", None, None), ("3", "2", None),
+                                                    ("8", "3", "2"), ("5", "4", "2"), ("7", "2", "2")])
+def test_short_launches_with_two_samples_per_team(chunk, segments, streams):
+    """kernels.hip::launch_blind_rotate cuts a batch into groups of `chunk` samples, the n CMUX iterations into `segments`
+    launches whose accumulators wait in global memory in between, and lets the two halves of a group alternate on two
+    streams (blind_rotate_plan); TFHE_BR_CHUNK, TFHE_BR_SEGMENTS and TFHE_BR_STREAMS override the plan.  With groups of 3, 2,
+    5, 7 and 8 samples a batch of 8 exercises the offsets of inputs, per-sample test vectors, parked accumulators and both
+    outputs, and -- at the shapes whose teams rotate two samples -- a last team that is one sample short in every odd launch
+    (with two streams: halves of 4 + 4, 3 + 2 and 4 + 3 samples; at two samples per team the first half is rounded up to
+    whole teams); with 2, 3 and 4 segments (n = 4, 2, 3: more segments than iterations are clamped) every launch but the
+    first resumes.  Three shapes against the oracle, in a child process (the variables are read once)."""
     import subprocess
     import sys
     import os
     here = os.path.dirname(os.path.abspath(__file__))
     env = dict(os.environ, TFHE_BR_CHUNK=chunk)
-    env.pop("TFHE_BR_SEGMENTS", None)
-    if segments:
-        env["TFHE_BR_SEGMENTS"] = segments
+    for name, value in (("TFHE_BR_SEGMENTS", segments), ("TFHE_BR_STREAMS", streams)):
+        env.pop(name, None)
+        if value:
+            env[name] = value
     run = subprocess.run([sys.executable, os.path.join(here, "br_chunk_probe.py")], env=env, capture_output=True, text=True,
                          timeout=600)
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]

@@ -140,7 +140,7 @@ hipError_t enqueue_blind_rotate(tfhe_context* ctx, const u32* lwe_in, size_t bat
   // accumulators between the launches of a segmented rotation: the caller's output, or the workspace (sized by reserve)
   u32* state = glwe_out ? glwe_out : (batch <= ctx->ws_batch ? ctx->d_glwe_c : nullptr);
   return launch::blind_rotate(ctx->stream, ctx->field, ctx->pbs, ctx->d_tw, lwe_in, batch, tv, tv_count == 1 ? 0 : ctx->N,
-                              ctx->d_bsk, glwe_out, lwe_extracted, state);
+                              ctx->d_bsk, glwe_out, lwe_extracted, state, &ctx->side);
 }
 
 // d_lwe_big: [batch][k*N+1] scratch of the reference order (unused when the key switch comes first)
@@ -392,6 +392,10 @@ int tfhe_context_create_with_backend(const tfhe_params* params, int device, int 
   if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
     return bail(e, "hipStreamCreate");
   ctx->own_stream = true;
+  if ((e = hipStreamCreateWithFlags(&ctx->side.stream, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipEventCreateWithFlags(&ctx->side.fork, hipEventDisableTiming)) != hipSuccess ||
+      (e = hipEventCreateWithFlags(&ctx->side.join, hipEventDisableTiming)) != hipSuccess)
+    return bail(e, "side stream");
   for (auto& slot : ctx->ev_ring)
     for (auto& ev : slot)
     if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e, "hipEventCreate");
@@ -441,6 +445,12 @@ void tfhe_context_destroy(tfhe_context* ctx) {
   for (auto& slot : ctx->ev_ring)
     for (auto& ev : slot)
     if (ev) (void)hipEventDestroy(ev);
+  if (ctx->side.stream) {
+    (void)hipStreamSynchronize(ctx->side.stream);
+    (void)hipStreamDestroy(ctx->side.stream);
+  }
+  if (ctx->side.fork) (void)hipEventDestroy(ctx->side.fork);
+  if (ctx->side.join) (void)hipEventDestroy(ctx->side.join);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }

@@ -19,6 +19,7 @@ struct tfhe_context {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  launch::SideStream side = {nullptr, nullptr, nullptr};  // the blind rotation's second stream (always the context's own)
   u32 N = 0, R = 0, big_n = 0;
 
   int field = 0;              // launch::kFieldGoldilocks | launch::kFieldFp64

@@ -867,63 +867,83 @@ hipError_t allow_lds(Kern kern, size_t bytes, std::atomic<unsigned long long>& d
   return e;
 }
 
-// Samples per blind-rotation launch.  The complex transform's kernel lives on an L2-hot key: 4,096 per launch when the
-// launch walks the whole key (in ONE launch of 131,072 the dispatcher refills finished teams one by one, every iteration of
-// the key is in use somewhere and it streams from the Infinity Cache: 75 k against 109 k PBS/s, round 2) -- but when the
-// rotation is cut into segments whose key slice the L2s hold whatever the teams' spread (blind_rotate_segments), LONG
-// launches win: fewer launch tails.  cfg4's share of 131,072: 118.3 k PBS/s in launches of 4,096, 128.9 k in one launch of
-// 64 segments; the 65,536-gate stream at the reference's defaults: 71.3 k -> 75.6 k gates/s (profiles/r03_kernel_ab.txt).
-// The prime-field kernels are VALU bound and lose 2.5 % to launch boundaries, so they only split beyond 2^20 (the grid is a
-// 32-bit number).  TFHE_BR_CHUNK overrides.
-constexpr size_t kLongBatch = 16384;  // from here on a batch goes out in long, segmented launches
-template <class F>
-inline size_t blind_rotate_chunk(size_t batch, bool can_segment, u32 log_n) {
-  static const size_t env_chunk = [] {
-    const char* env = std::getenv("TFHE_BR_CHUNK");
-    const long v = env ? std::atol(env) : 0;
-    return v > 0 ? (size_t)v : (size_t)0;
-  }();
-  if (env_chunk) return env_chunk;
-  if (!F::kLogShrink) return (size_t)1 << 20;
-  if (can_segment && batch >= kLongBatch) return log_n >= 11 ? (size_t)16384 : (size_t)131072;
-  return 4096;
+// How a batch's blind rotations go out (launch_blind_rotate).
+//   chunk     samples per group of launches
+//   segments  launches per rotation: each walks key rows [i0, i1) only and parks the accumulators in global memory
+//   streams   2: the two halves of a chunk go out on two streams, segment by segment in turn
+// Why.  A team reads GGSW_i once per iteration (cfg2: 197 KB, 124 MB per rotation; the reference's defaults: 442 KB,
+// 319 MB; N = 2048 with k = 2: 1.2 MB, 743 MB) and the complex transform's kernels draw 13-15 TB/s of it: that is L2
+// bandwidth, and only while the teams that run at the same time read the SAME rows.  A launch of 4,096 samples is four
+// rounds of the 1,024 teams the chip holds, and the dispatcher refills them one by one: teams of different rounds are at
+// different iterations, most of the key is in use somewhere, and it comes from the Infinity Cache -- or, when it is larger
+// than that (> 256 MiB), from HBM, again and again (PMC, cfg3: 258 GB per launch = 4 TB/s).  Round 2 kept launches short
+// for that reason (4,096 samples: 109 k PBS/s at cfg2 against 75 k in one launch of 131,072).  Round 3 blocks the key
+// instead (profiles/r03_kernel_ab.txt):
+//   - SEGMENT launches: all teams of a launch, whatever their round, read the same slice of the key; a slice of a few MB
+//     stays in the L2s.  Batch 4,096 on one stream: cfg3 62.2 k -> 71.2 k PBS/s from 32 segments on, cfg5 18.8 k -> 20.95 k
+//     from 4 on (slices of <= 186 MB: the Infinity Cache holds them; no more from smaller ones), cfg2 and cfg1 (124 and
+//     33 MB: they fit as they are) nothing: what the slices gain, every launch's tail -- the chip draining while the last
+//     teams finish -- takes back.
+//   - TWO STREAMS: the halves of the batch alternate, so one half's tail is filled by the other half's next launch.
+//     Batch 4,096 with slices of 2 MiB: cfg2 117.6 k -> 125.2 k, cfg3 71.2 k -> 77.9 k, cfg1 358 k -> 387 k; it pays
+//     as soon as the batch exceeds the teams the chip holds at once (at exactly that many it loses 2-4 %); three and
+//     four streams add nothing; cfg5's 12-wave teams (one per CU) gain nothing either.
+//   - with L2-sized slices launches can be LONG: cfg4's 131,072: 118.3 k in launches of 4,096 -> 128-130 k in one group.
+//   (Measured and dropped: the same blocking inside ONE persistent launch -- teams that are never re-dispatched never
+//   re-synchronise, 48 k at cfg3.)
+// Hence, at N <= 1024: batches above what the chip holds at once go out in groups of up to 131,072 samples over key slices
+// of 2 MiB, on two streams; smaller ones in one launch.  That holds for every field (two streams + slices at batch 4,096:
+// fp64-p49 at the reference's defaults 54.2 k -> 60.7 k PBS/s, Goldilocks at cfg2 29.2 k -> 30.8 k, fp64-p42 at cfg2 75.6 k
+// -> 77.0 k).  At N = 2048: slices of 128 MiB if the key exceeds the Infinity Cache, one stream; the complex transform's
+// long batches in groups of 16,384.  Without a place to park accumulators (state == nullptr): whole rotations, 4,096
+// samples per launch for the complex transform (round 2: 109 k against 75 k PBS/s in one launch of 131,072), one launch
+// for the prime fields (VALU-bound, they lose 2.5 % to launch boundaries).
+// At least 4 iterations per segment.  TFHE_BR_CHUNK, TFHE_BR_SEGMENTS and TFHE_BR_STREAMS override (tests, sweeps).
+struct BlindRotatePlan {
+  size_t chunk;
+  u32 segments;
+  int streams;
+};
+inline long env_number(const char* name) {
+  const char* env = std::getenv(name);
+  const long v = env ? std::atol(env) : 0;
+  return v > 0 ? v : 0;
 }
-
-// Launches per blind rotation.  A launch that walks the WHOLE prepared key sweeps it once per round of resident teams, and
-// teams that drift apart -- or that belong to different rounds -- sit at different iterations: when the key does not fit
-// the 256 MiB Infinity Cache (the reference's default parameters: 319 MB; N = 2048, k = 2: 743 MB) a good part of it
-// streams from HBM again and again (PMC, cfg3: 258 GB per launch = 4 TB/s).  Cutting the n iterations into segments
-// -- every launch walks only key rows [i0, i1) and parks the accumulators in global memory -- blocks the key for the
-// caches.  Measured (profiles/r03_kernel_ab.txt), batch 4,096: cfg3 62.2 k -> 71.2 k PBS/s from 32 segments on (slices of
-// <= 10 MB: the L2s hold them), cfg5 18.8 k -> 20.95 k from 4 on (slices of <= 186 MB: the Infinity Cache holds them; no more
-// from smaller ones), cfg2 and cfg1 (124 and 33 MB: they fit as they are) nothing or a loss.  Long launches (blind_rotate_chunk)
-// want L2-sized slices whatever the key's size: best at 1.9-2.7 MB.  Hence: slices of 128 MiB at N = 2048; below, slices of
-// 2 MiB in long launches, and of 8 MiB in launches of 4,096 if the key does not fit the Infinity Cache with room to spare.
-// At least 4 iterations per segment.  TFHE_BR_SEGMENTS overrides the count.
-inline u32 blind_rotate_segments(u32 n, size_t key_bytes, u32 log_n, bool long_launch) {
-  static const u32 env_segments = [] {
-    const char* env = std::getenv("TFHE_BR_SEGMENTS");
-    const long v = env ? std::atol(env) : 0;
-    return v > 0 ? (u32)v : 0u;
-  }();
-  u32 segments = env_segments;
-  if (segments == 0) {
-    const bool fits = key_bytes <= ((size_t)224 << 20);
+template <class F>
+inline BlindRotatePlan blind_rotate_plan(size_t batch, bool can_park, bool have_side, u32 n, size_t key_bytes, u32 log_n,
+                                         size_t resident_samples) {
+  static const long env_chunk = env_number("TFHE_BR_CHUNK"), env_segments = env_number("TFHE_BR_SEGMENTS"),
+                    env_streams = env_number("TFHE_BR_STREAMS");
+  BlindRotatePlan plan{F::kLogShrink ? (size_t)4096 : (size_t)1 << 20, 1u, 1};
+  if (can_park) {
+    const bool fits = key_bytes <= ((size_t)224 << 20);  // the Infinity Cache, with room for the accumulators
     size_t slice = 0;
-    if (log_n >= 11) slice = fits ? 0 : (size_t)128 << 20;
-    else if (long_launch) slice = (size_t)2 << 20;
-    else slice = fits ? 0 : (size_t)8 << 20;
-    segments = slice ? (u32)((key_bytes + slice - 1) / slice) : 1u;
-    if (segments > n / 4) segments = n / 4;
+    if (log_n >= 11) {
+      slice = fits ? 0 : (size_t)128 << 20;
+      if (F::kLogShrink && batch >= 16384) plan.chunk = 16384;
+    } else if (batch > resident_samples) {
+      slice = (size_t)2 << 20;
+      plan.chunk = 131072;
+      plan.streams = have_side ? 2 : 1;
+    } else {
+      plan.chunk = batch ? batch : 1;
+    }
+    if (env_streams) plan.streams = have_side && env_streams >= 2 ? 2 : 1;
+    if (plan.streams == 2 && slice == 0) slice = (size_t)2 << 20;
+    plan.segments = slice ? (u32)((key_bytes + slice - 1) / slice) : 1u;
+    if (plan.segments > n / 4) plan.segments = n / 4;
+    if (env_segments) plan.segments = (u32)env_segments;
+    if (plan.segments > n) plan.segments = n;
+    if (plan.segments < 1) plan.segments = 1;
   }
-  if (segments > n) segments = n;
-  return segments ? segments : 1u;
+  if (env_chunk) plan.chunk = (size_t)env_chunk;
+  return plan;
 }
 
 template <class F, int LOGN, int K>
 hipError_t launch_blind_rotate(hipStream_t s, const PbsParams& P, const void* tw_v, const u32* lwe_in,
                                size_t batch, const u32* tv, size_t tv_stride, const void* bsk_v,
-                               u32* glwe_out, u32* lwe_extracted, u32* state) {
+                               u32* glwe_out, u32* lwe_extracted, u32* state, const launch::SideStream* side) {
   if constexpr (!field_shape_ok<F, LOGN>()) {
     return hipErrorInvalidValue;  // the context never picks such a field (capi.cpp)
   } else {
@@ -936,7 +956,7 @@ hipError_t launch_blind_rotate(hipStream_t s, const PbsParams& P, const void* tw
       static std::atomic<unsigned long long> split_lds_done{0};
       hipError_t se = allow_lds(skern, SC::kLds, split_lds_done);
       if (se != hipSuccess) return se;
-      const size_t schunk = blind_rotate_chunk<F>(batch, false, (u32)LOGN);
+      const size_t schunk = 4096;
       for (size_t off = 0; off < batch; off += schunk) {
         const size_t here = batch - off < schunk ? batch - off : schunk;
         hipLaunchKernelGGL(skern, dim3((unsigned)((here + 1) / 2)), dim3(SC::kThreads), SC::kLds, s, P, tw,
@@ -952,30 +972,58 @@ hipError_t launch_blind_rotate(hipStream_t s, const PbsParams& P, const void* tw
     static std::atomic<unsigned long long> lds_done{0};
     hipError_t e = allow_lds(kern, C::kLds, lds_done);
     if (e != hipSuccess) return e;
-    // Long batches go out in launches of blind_rotate_chunk<F>() samples.  All teams of a launch walk the key in
-    // step (GGSW_i is read by every team at about the same time and stays hot in the L2s); in ONE launch of
-    // 131,072 samples the dispatcher refills finished teams one by one, after a few thousand samples every
-    // iteration of the key is in use somewhere and the 124 MB key streams from the Infinity Cache instead:
-    // the complex-FFT kernel, which needs 13 TB/s of key, ran 75.0 k PBS/s that way against 108.9 k at 4,096
-    // (profiles/r02_f_*).  Launches on one stream run back to back.
-    const size_t chunk = blind_rotate_chunk<F>(batch, state != nullptr, (u32)LOGN);
-    // ... and a launch may cover only a SEGMENT of the n CMUX iterations (blind_rotate_segments): the key slice it walks
-    // stays in the caches whatever the spread of its teams
+    // teams the chip holds at once (occupancy x CUs), asked once per instantiation
+    static std::atomic<unsigned> resident_teams{0};
+    unsigned capacity = resident_teams.load(std::memory_order_acquire);
+    if (capacity == 0) {
+      int per_cu = 0, dev = 0, cus = 0;
+      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, C::kThreads, C::kLds);
+      if (e != hipSuccess) return e;
+      if (hipGetDevice(&dev) != hipSuccess ||
+          hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        cus = 256;
+      capacity = (unsigned)(per_cu > 0 ? per_cu : 1) * (unsigned)(cus > 0 ? cus : 256);
+      resident_teams.store(capacity, std::memory_order_release);
+    }
+    // a second stream cannot be forked inside a stream capture that the caller ends on `s` alone without it joining;
+    // it does join (below), but a capture is no place for a measured policy: one stream there
+    bool have_side = side && side->stream && side->fork && side->join;
+    if (have_side) {
+      hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(s, &capturing) != hipSuccess || capturing != hipStreamCaptureStatusNone) have_side = false;
+    }
     const size_t key_bytes = (size_t)P.n * (K + 1) * P.levels * (K + 1) * F::kParts * C::N * 8;
-    const u32 segments = state ? blind_rotate_segments(P.n, key_bytes, (u32)LOGN, chunk >= kLongBatch && batch >= kLongBatch) : 1u;
-    const u32 per = (P.n + segments - 1) / segments;
-    for (size_t off = 0; off < batch; off += chunk) {
-      const size_t here = batch - off < chunk ? batch - off : chunk;
+    const BlindRotatePlan plan =
+        blind_rotate_plan<F>(batch, state != nullptr, have_side, P.n, key_bytes, (u32)LOGN, (size_t)capacity * C::S);
+    const int parts = plan.streams == 2 && plan.segments > 1 ? 2 : 1;
+    const u32 per = (P.n + plan.segments - 1) / plan.segments;
+    if (parts == 2) {  // fork: the side stream starts after everything already on s
+      if ((e = hipEventRecord(side->fork, s)) != hipSuccess) return e;
+      if ((e = hipStreamWaitEvent(side->stream, side->fork, 0)) != hipSuccess) return e;
+    }
+    for (size_t off = 0; off < batch; off += plan.chunk) {
+      const size_t here = batch - off < plan.chunk ? batch - off : plan.chunk;
+      // part q = samples [q * share, (q + 1) * share) of the chunk; share is a multiple of the samples per team
+      const size_t share = (((here + parts - 1) / parts + C::S - 1) / C::S) * C::S;
       for (u32 i0 = 0; i0 < P.n; i0 += per) {
         const u32 i1 = i0 + per < P.n ? i0 + per : P.n;
-        hipLaunchKernelGGL(kern, dim3((unsigned)((here + C::S - 1) / C::S)), dim3(C::kThreads), C::kLds, s, P, tw,
-                           lwe_in + off * ((size_t)P.n + 1), here, tv + off * tv_stride, tv_stride, bsk,
-                           glwe_out ? glwe_out + off * (size_t)(K + 1) * C::N : nullptr,
-                           lwe_extracted ? lwe_extracted + off * ((size_t)K * C::N + 1) : nullptr, i0, i1,
-                           state ? state + off * (size_t)(K + 1) * C::N : nullptr);
-        e = hipGetLastError();
-        if (e != hipSuccess) return e;
+        for (int q = 0; q < parts; ++q) {
+          if ((size_t)q * share >= here) break;
+          const size_t o = off + (size_t)q * share;
+          const size_t cnt = here - (size_t)q * share < share ? here - (size_t)q * share : share;
+          hipLaunchKernelGGL(kern, dim3((unsigned)((cnt + C::S - 1) / C::S)), dim3(C::kThreads), C::kLds,
+                             q ? side->stream : s, P, tw, lwe_in + o * ((size_t)P.n + 1), cnt, tv + o * tv_stride,
+                             tv_stride, bsk, glwe_out ? glwe_out + o * (size_t)(K + 1) * C::N : nullptr,
+                             lwe_extracted ? lwe_extracted + o * ((size_t)K * C::N + 1) : nullptr, i0, i1,
+                             state ? state + o * (size_t)(K + 1) * C::N : nullptr);
+          e = hipGetLastError();
+          if (e != hipSuccess) return e;
+        }
       }
+    }
+    if (parts == 2) {  // join: whatever follows on s waits for the side stream
+      if ((e = hipEventRecord(side->join, side->stream)) != hipSuccess) return e;
+      if ((e = hipStreamWaitEvent(s, side->join, 0)) != hipSuccess) return e;
     }
     return hipSuccess;
   }
@@ -1208,10 +1256,10 @@ hipError_t bsk_prepare(hipStream_t s, int field, u32 log_n, const void* tw, cons
 
 hipError_t blind_rotate(hipStream_t s, int field, const PbsParams& P, const void* tw,
                         const u32* lwe_in, size_t batch, const u32* tv, size_t tv_stride,
-                        const void* bsk, u32* glwe_out, u32* lwe_extracted, u32* state) {
+                        const void* bsk, u32* glwe_out, u32* lwe_extracted, u32* state, const SideStream* side) {
   TFHE_DISPATCH_FIELD(field, TFHE_DISPATCH_LOGN_K(P.log_n, P.k,
                       (launch_blind_rotate<FF, LL, KK>(s, P, tw, lwe_in, batch, tv, tv_stride, bsk,
-                                                       glwe_out, lwe_extracted, state))));
+                                                       glwe_out, lwe_extracted, state, side))));
 }
 
 hipError_t blind_rotate_bmmp(hipStream_t s, int field, const PbsParams& P, const void* tw,

@@ -28,13 +28,22 @@ int samples_per_team(int field, u32 log_n, u32 k);
 hipError_t bsk_prepare(hipStream_t s, int field, u32 log_n, const void* tw, const u32* polys,
                        size_t poly_count, void* spectra);
 
+// A second stream of the caller's, with the two events that fork it from and join it to the main one: batches larger than
+// what the chip holds at once go out as two halves whose segment launches alternate (kernels.hip::blind_rotate_plan).
+struct SideStream {
+  hipStream_t stream;
+  hipEvent_t fork, join;
+};
+
 // Blind rotation of `batch` samples.  Optional outputs: glwe_out [batch][k+1][N] and/or
 // lwe_extracted [batch][k*N+1] (sample extract at index 0 fused in).
 // `state`: [batch][k+1][N] words of scratch that hold the accumulators between the launches of a segmented rotation
-// (may be glwe_out itself; null: one launch per rotation).
+// (may be glwe_out itself; null: one launch per rotation).  `side`: null = everything on s.  On return all work is
+// ordered on s (the side stream has been joined).
 hipError_t blind_rotate(hipStream_t s, int field, const PbsParams& P, const void* tw,
                         const u32* lwe_in, size_t batch, const u32* tv, size_t tv_stride,
-                        const void* bsk, u32* glwe_out, u32* lwe_extracted, u32* state = nullptr);
+                        const void* bsk, u32* glwe_out, u32* lwe_extracted, u32* state = nullptr,
+                        const SideStream* side = nullptr);
 
 // The unrolled blind rotation of notes/BMMP Bootstrapping.md (two key bits per step): bsk holds
 // n/2 * 3 prepared GGSWs (pbs_wave.h::blind_rotate_bmmp_team); n even, shape_supported_bmmp only.
