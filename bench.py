@@ -552,7 +552,11 @@ def main():
             "valu": valu_view,  # VALU-issue view from the same PMC passes (SURVEY 8d asks for both)
             "hbm_copy_measured_GBps": hbm_copy,
             "frac_of_measured_hbm": achieved / hbm_copy,
+            # kernel_ms: HIP events on the context's stream around ALL blind-rotation launches of one step (launch_plan:
+            # a batch larger than the chip goes out as `segments` launches per rotation -- one slice of the key each -- on
+            # `streams` alternating streams, joined before the closing event); "per launch" below = per step's rotations
             "kernel_ms": br_avg,
+            "launch_plan": ctx.blind_rotate_plan(batch),
             "algorithmic_bytes_per_launch": algo_bytes,
             "external_products_per_s": ext_products / (br_avg * 1e-3),
             "key_switch_kernel_ms": ks_avg,

@@ -107,7 +107,10 @@ const char *tfhe_context_backend(const tfhe_context *ctx);
 void tfhe_context_destroy(tfhe_context *ctx);
 /* Run on an existing hipStream_t, e.g. torch.cuda.current_stream().cuda_stream.  A NULL handle is
  * HIP's default stream (that is what torch hands out unless the caller switched streams).  A new
- * context starts on a private non-blocking stream; tfhe_context_use_own_stream goes back to one. */
+ * context starts on a private non-blocking stream; tfhe_context_use_own_stream goes back to one.
+ * Whatever the stream, everything a call enqueues is ordered on it: the blind rotation of a large batch
+ * forks half of its launches onto a second, context-owned stream and joins it again before the call
+ * returns (events; tfhe_debug_blind_rotate_plan).  During a stream capture it stays on the one stream. */
 int tfhe_context_set_stream(tfhe_context *ctx, void *hip_stream);
 int tfhe_context_use_own_stream(tfhe_context *ctx);
 int tfhe_context_synchronize(tfhe_context *ctx);
@@ -410,6 +413,15 @@ int tfhe_measure_hbm_copy(tfhe_context *ctx, size_t bytes, int reps, double *gb_
  * beside the product library, never loaded by it) records it; the product library returns TFHE_ERR_UNSUPPORTED.
  * Synchronises the device. */
 int tfhe_debug_fft_margin(tfhe_context *ctx, double *worst, int reset);
+
+/* How tfhe_bootstrap_batch[_device] sends out the blind rotations of a batch of this size (no reference counterpart;
+ * bench lines and tests).  A batch larger than what the chip rotates at once (*resident_samples) goes out in groups of
+ * *samples_per_group samples; every rotation is cut into *segments launches that walk a slice of the bootstrapping key each
+ * (the accumulators wait in the context's workspace in between: tfhe_context_reserve), and with *streams == 2 the two
+ * halves of a group alternate on the context's stream and a second stream of its own, which is joined before the call
+ * returns -- the caller still orders everything on the one stream it gave (tfhe_context_set_stream). */
+int tfhe_debug_blind_rotate_plan(tfhe_context *ctx, size_t batch, size_t *samples_per_group, unsigned *segments,
+                                 unsigned *streams, size_t *resident_samples);
 
 /* Library / build identification */
 const char *tfhe_version(void);

@@ -612,6 +612,28 @@ def test_short_launches_with_two_samples_per_team(chunk, segments, streams):
     assert "short launches parity True" in run.stdout
 
 
+def test_blind_rotate_plan_matches_its_description(oracle):
+    """tfhe_debug_blind_rotate_plan: a batch the chip rotates at once goes out as one launch; a larger one at N <= 1024 as
+    key slices of 2 MiB on two streams (kernels.hip::blind_rotate_plan).  The full-size parity tests run under exactly
+    these plans; this pins the numbers the bench line and DESIGN.md quote."""
+    m = pkg()
+    p = oracle.Params(1, 10, 630, oracle.Decomposer(7, 3), oracle.Decomposer(2, 8), log_p=2)  # cfg2
+    with m.Context(to_pkg_params(p)) as ctx:
+        small = ctx.blind_rotate_plan(8)
+        assert small["segments"] == 1 and small["streams"] == 1 and small["launches"] == 1
+        resident = small["resident_samples"]
+        assert resident >= 256  # at least one team per CU
+        at = ctx.blind_rotate_plan(resident)
+        assert at["segments"] == 1 and at["streams"] == 1
+        big = ctx.blind_rotate_plan(4096)
+        assert 4096 > resident and big["streams"] == 2
+        key_bytes = 630 * 2 * 3 * 2 * 2 * 1024 * 8  # n (k+1) l (k+1) parts N 8
+        per = -(-630 // -(-key_bytes // (2 << 20)))  # iterations per launch: slices of at most 2 MiB -> 60 -> 11 iterations
+        assert per == 11 and big["segments"] == -(-630 // per) == 58
+        assert big["groups"] == 1 and big["launches"] == 116
+        assert ctx.blind_rotate_plan(1 << 20)["groups"] == 8  # groups of 131,072
+
+
 def test_encrypted_adder_gate_graph(oracle):
     """a graph of AND/OR/XOR gates evaluated with all ciphertexts resident on the device
     (tfhe_gate_batch_device, gates of one level batched): 32 independent 4-bit ripple-carry adders

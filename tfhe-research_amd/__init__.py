@@ -415,6 +415,16 @@ class Context:
         self._check(lib().tfhe_debug_fft_margin(self._h, C.byref(out), C.c_int(int(reset))))
         return out.value
 
+    def blind_rotate_plan(self, batch: int) -> dict:
+        """how a bootstrap of `batch` samples sends out its blind rotations (tfhe_debug_blind_rotate_plan)"""
+        group, resident = C.c_size_t(), C.c_size_t()
+        segments, streams = C.c_uint(), C.c_uint()
+        self._check(lib().tfhe_debug_blind_rotate_plan(self._h, C.c_size_t(batch), C.byref(group), C.byref(segments),
+                                                       C.byref(streams), C.byref(resident)))
+        groups = -(-batch // max(1, group.value))
+        return {"samples_per_group": group.value, "groups": groups, "segments": segments.value, "streams": streams.value,
+                "launches": groups * segments.value * streams.value, "resident_samples": resident.value}
+
     def last_kernel_ms(self):
         br, ks = C.c_float(), C.c_float()
         self._check(lib().tfhe_last_kernel_ms(self._h, C.byref(br), C.byref(ks)))

@@ -558,6 +558,22 @@ int tfhe_debug_fft_margin(tfhe_context* ctx, double* worst, int reset) {
 #endif
 }
 
+int tfhe_debug_blind_rotate_plan(tfhe_context* ctx, size_t batch, size_t* samples_per_group, unsigned* segments,
+                                 unsigned* streams, size_t* resident_samples) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  if (!samples_per_group || !segments || !streams || !resident_samples) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer");
+  launch::BlindRotatePlanInfo plan{};
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  // the plan of tfhe_bootstrap_batch[_device], which reserve the workspace the accumulators are parked in
+  HIP_TRY(ctx, launch::blind_rotate_plan(ctx->field, ctx->pbs, batch, !ctx->bmmp, ctx->side.stream != nullptr, &plan));
+  *samples_per_group = plan.chunk;
+  *segments = ctx->bmmp ? 1u : plan.segments;
+  *streams = ctx->bmmp ? 1u : (unsigned)plan.streams;
+  *resident_samples = plan.resident_samples;
+  return TFHE_OK;
+}
+
 int tfhe_kernel_ms_ago(tfhe_context* ctx, unsigned steps_ago, float* blind_rotate_ms, float* key_switch_ms) {
   int st = check_ctx(ctx);
   if (st) return st;

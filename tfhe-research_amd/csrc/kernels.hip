@@ -935,9 +935,54 @@ inline BlindRotatePlan blind_rotate_plan(size_t batch, bool can_park, bool have_
     if (env_segments) plan.segments = (u32)env_segments;
     if (plan.segments > n) plan.segments = n;
     if (plan.segments < 1) plan.segments = 1;
+    const u32 per = (n + plan.segments - 1) / plan.segments;  // iterations per launch ...
+    plan.segments = (n + per - 1) / per;                      // ... and the launches that makes
   }
   if (env_chunk) plan.chunk = (size_t)env_chunk;
   return plan;
+}
+
+// teams of blind_rotate_kernel<F, LOGN, K> the chip holds at once (occupancy x CUs), asked once per instantiation
+template <class F, int LOGN, int K>
+hipError_t resident_teams(unsigned* out) {
+  using C = TeamCfg<F, LOGN, K>;
+  static std::atomic<unsigned> cached{0};
+  unsigned capacity = cached.load(std::memory_order_acquire);
+  if (capacity == 0) {
+    auto kern = blind_rotate_kernel<F, LOGN, K>;
+    int per_cu = 0, dev = 0, cus = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, C::kThreads, C::kLds);
+    if (e != hipSuccess) return e;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      cus = 256;
+    capacity = (unsigned)(per_cu > 0 ? per_cu : 1) * (unsigned)(cus > 0 ? cus : 256);
+    cached.store(capacity, std::memory_order_release);
+  }
+  *out = capacity;
+  return hipSuccess;
+}
+
+template <class F, int LOGN, int K>
+hipError_t plan_blind_rotate(const PbsParams& P, size_t batch, bool can_park, bool have_side, launch::BlindRotatePlanInfo* out) {
+  if constexpr (!field_shape_ok<F, LOGN>()) {
+    return hipErrorInvalidValue;
+  } else {
+    using C = TeamCfg<F, LOGN, K>;
+    static std::atomic<unsigned long long> lds_done{0};
+    hipError_t e = allow_lds(blind_rotate_kernel<F, LOGN, K>, C::kLds, lds_done);
+    unsigned capacity = 0;
+    if (e == hipSuccess) e = resident_teams<F, LOGN, K>(&capacity);
+    if (e != hipSuccess) return e;
+    const size_t key_bytes = (size_t)P.n * (K + 1) * P.levels * (K + 1) * F::kParts * C::N * 8;
+    const BlindRotatePlan plan = blind_rotate_plan<F>(batch, can_park, have_side, P.n, key_bytes, (u32)LOGN, (size_t)capacity * C::S);
+    out->chunk = plan.chunk;
+    out->segments = plan.segments;
+    out->streams = plan.streams == 2 && plan.segments > 1 ? 2 : 1;
+    out->resident_samples = (size_t)capacity * C::S;
+    out->samples_per_team = C::S;
+    return hipSuccess;
+  }
 }
 
 template <class F, int LOGN, int K>
@@ -972,19 +1017,8 @@ hipError_t launch_blind_rotate(hipStream_t s, const PbsParams& P, const void* tw
     static std::atomic<unsigned long long> lds_done{0};
     hipError_t e = allow_lds(kern, C::kLds, lds_done);
     if (e != hipSuccess) return e;
-    // teams the chip holds at once (occupancy x CUs), asked once per instantiation
-    static std::atomic<unsigned> resident_teams{0};
-    unsigned capacity = resident_teams.load(std::memory_order_acquire);
-    if (capacity == 0) {
-      int per_cu = 0, dev = 0, cus = 0;
-      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, C::kThreads, C::kLds);
-      if (e != hipSuccess) return e;
-      if (hipGetDevice(&dev) != hipSuccess ||
-          hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-        cus = 256;
-      capacity = (unsigned)(per_cu > 0 ? per_cu : 1) * (unsigned)(cus > 0 ? cus : 256);
-      resident_teams.store(capacity, std::memory_order_release);
-    }
+    unsigned capacity = 0;
+    if ((e = resident_teams<F, LOGN, K>(&capacity)) != hipSuccess) return e;
     // a second stream cannot be forked inside a stream capture that the caller ends on `s` alone without it joining;
     // it does join (below), but a capture is no place for a measured policy: one stream there
     bool have_side = side && side->stream && side->fork && side->join;
@@ -1260,6 +1294,11 @@ hipError_t blind_rotate(hipStream_t s, int field, const PbsParams& P, const void
   TFHE_DISPATCH_FIELD(field, TFHE_DISPATCH_LOGN_K(P.log_n, P.k,
                       (launch_blind_rotate<FF, LL, KK>(s, P, tw, lwe_in, batch, tv, tv_stride, bsk,
                                                        glwe_out, lwe_extracted, state, side))));
+}
+
+hipError_t blind_rotate_plan(int field, const PbsParams& P, size_t batch, bool can_park, bool have_side,
+                             BlindRotatePlanInfo* out) {
+  TFHE_DISPATCH_FIELD(field, TFHE_DISPATCH_LOGN_K(P.log_n, P.k, (plan_blind_rotate<FF, LL, KK>(P, batch, can_park, have_side, out))));
 }
 
 hipError_t blind_rotate_bmmp(hipStream_t s, int field, const PbsParams& P, const void* tw,

@@ -45,6 +45,17 @@ hipError_t blind_rotate(hipStream_t s, int field, const PbsParams& P, const void
                         const void* bsk, u32* glwe_out, u32* lwe_extracted, u32* state = nullptr,
                         const SideStream* side = nullptr);
 
+// How blind_rotate would send out a batch (kernels.hip::blind_rotate_plan), for bench lines and tests
+struct BlindRotatePlanInfo {
+  size_t chunk;             // samples per group of launches
+  u32 segments;             // launches per rotation (key slices)
+  int streams;              // 1 or 2
+  size_t resident_samples;  // samples the chip rotates at once (teams it holds x samples per team)
+  int samples_per_team;
+};
+hipError_t blind_rotate_plan(int field, const PbsParams& P, size_t batch, bool can_park, bool have_side,
+                             BlindRotatePlanInfo* out);
+
 // The unrolled blind rotation of notes/BMMP Bootstrapping.md (two key bits per step): bsk holds
 // n/2 * 3 prepared GGSWs (pbs_wave.h::blind_rotate_bmmp_team); n even, shape_supported_bmmp only.
 bool shape_supported_bmmp(u32 log_n, u32 k);

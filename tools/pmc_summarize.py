@@ -3,6 +3,8 @@ tools/profile_pmc.sh leaves under gpurun_out/<tag>/ and prints the summary commi
 profiles/ (plus, with --json, the traffic figure bench.py reports in roofline.traffic).
     python tools/pmc_summarize.py gpurun_out/final/pmc "cfg2 batch 4096" 4096 630 65536 [--json profiles/pmc_traffic.json]
         [--kernel external_product] [--source profiles/<the file this output is committed as>]
+        [--steps 1: the pass ran that many steps and a step's blind rotations are SEVERAL launches (key slices, two streams:
+        kernels.hip::blind_rotate_plan) -- sum the dispatches and divide by the steps instead of averaging per dispatch]
         [--bench-kernel 'blind_rotate_kernel<fp64-fft,10,1>'] [--mix fma,mul,add,rndne,cvt,int]  (instruction mix per wave
         and iteration from tools/isa_report.py, for the issue floor; default: the 42-bit field's cfg2 kernel)
 (for the standalone external-product kernel pass n = 1: one product per sample and launch)
@@ -26,6 +28,7 @@ source = sys.argv[sys.argv.index("--source") + 1] if "--source" in sys.argv else
 MIX = [int(x) for x in (sys.argv[sys.argv.index("--mix") + 1] if "--mix" in sys.argv else "1200,1140,1472,584,48,643").split(",")]
 FLOOR = (MIX[0] * 4.78 + MIX[1] * 4.48 + MIX[2] * 4.48 + MIX[3] * 4.34 + MIX[4] * 4.8 + MIX[5] * 4.4) / sum(MIX)
 BENCH_KERNEL = sys.argv[sys.argv.index("--bench-kernel") + 1] if "--bench-kernel" in sys.argv else "blind_rotate_kernel<fp64-p42,10,1>"
+STEPS = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else 0
 tot = defaultdict(float)
 launches = defaultdict(set)
 kernel = None
@@ -42,12 +45,18 @@ for name in ("fetch", "write", "sq", "sq2"):
         launches[r["Counter_Name"]].add(r["Dispatch_Id"])
 print(f"# rocprofv3 --pmc passes (separate runs: FETCH_SIZE | WRITE_SIZE | SQ set 1 | SQ set 2), bench.py --steps 1, {label}")
 print("# FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 1/2 of wide coalesced reads (MI355X_MICROARCH.md, HBM);")
-print("# both count the L2's fabric-side requests, Infinity-Cache hits included (same guide).  Values are per launch.")
+print("# both count the L2's fabric-side requests, Infinity-Cache hits included (same guide).  Values are per "
+      + ("launch." if not STEPS else "STEP = the sum over all blind-rotation dispatches of one step"))
 print(f"# kernel: {kernel}")
 per = {}
 for k in sorted(tot):
-    per[k] = tot[k] / max(1, len(launches[k]))
+    per[k] = tot[k] / (STEPS if STEPS else max(1, len(launches[k])))
     print(f"{k}\t{per[k]:.0f}")
+if STEPS:
+    counts = sorted({len(v) for v in launches.values()})
+    print(f"# dispatches per step: {', '.join(str(c // STEPS) for c in counts)} (a rotation is cut into key slices, the halves of the batch "
+          "alternate on two streams; under --pmc the dispatches run one after the other, so the cycle counts below include every "
+          "launch's tail, which the two streams hide in a normal run)")
 products = batch * n
 if "FETCH_SIZE" in per and "WRITE_SIZE" in per:
     traffic = (2 * per["FETCH_SIZE"] + per["WRITE_SIZE"]) * 1024
