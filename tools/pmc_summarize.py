@@ -54,13 +54,14 @@ for k in sorted(tot):
     print(f"{k}\t{per[k]:.0f}")
 if STEPS:
     counts = sorted({len(v) for v in launches.values()})
-    print(f"# dispatches per step: {', '.join(str(c // STEPS) for c in counts)} (a rotation is cut into key slices, the halves of the batch "
-          "alternate on two streams; under --pmc the dispatches run one after the other, so the cycle counts below include every "
-          "launch's tail, which the two streams hide in a normal run)")
+    per_step = counts[0] // STEPS
+    print(f"# dispatches per step: {per_step}" + (" (a rotation is cut into key slices, the halves of the batch alternate on two streams; under "
+          "--pmc the dispatches run one after the other, so the cycle counts below include every launch's tail, which the two "
+          "streams hide in a normal run)" if per_step > 1 else " (the whole rotation of the batch in one launch)"))
 products = batch * n
 if "FETCH_SIZE" in per and "WRITE_SIZE" in per:
     traffic = (2 * per["FETCH_SIZE"] + per["WRITE_SIZE"]) * 1024
-    print(f"# derived: fabric traffic per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 = {traffic / 1e9:.1f} GB "
+    print(f"# derived: fabric traffic per {'step' if STEPS else 'launch'} = (2*FETCH_SIZE + WRITE_SIZE)*1024 = {traffic / 1e9:.1f} GB "
           f"(algorithmic {products * algo_bytes / 1e9:.1f} GB)")
 if "SQ_INSTS_VALU" in per:
     print(f"# derived: VALU instructions per external product = {per['SQ_INSTS_VALU'] / products:.0f}")
