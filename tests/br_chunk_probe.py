@@ -1,5 +1,5 @@
 """Child process of tests/test_gpu_parity.py::test_short_launches_with_two_samples_per_team: the blind rotation of a batch
-goes out in launches of TFHE_BR_CHUNK samples (kernels.hip::blind_rotate_chunk reads the variable once per process, hence
+goes out in launches of TFHE_BR_CHUNK samples (kernels.hip::blind_rotate_plan reads the variables once per process, hence
 the child); with an ODD chunk every launch of a two-samples-per-team kernel ends in a team that is one sample short."""
 import os
 import sys

@@ -21,7 +21,7 @@ using namespace tfhe;
 namespace {
 
 int g_exchange_buffers = 1;  // exchange buffers per group (kernels.hip::ExchangeBuffersOf)
-int g_segments = 1;  // launches a blind rotation is cut into (kernels.hip::blind_rotate_segments): resumes from parked accumulators
+int g_segments = 1;  // launches a blind rotation is cut into (kernels.hip::blind_rotate_plan): resumes from parked accumulators
 int g_samples_per_team = 1;  // samples a team rotates at once (kernels.hip::SamplesPerTeam): each needs a buffer and an accumulator
 
 template <class Elem>

@@ -470,7 +470,7 @@ TFHE_HD void external_product_team(const Ctx& c, const PbsParams& P, const typen
 // start at 0 resumes from the GLWE accumulators the previous one left in global memory (resume[s]: [K+1][N] of sample
 // s), and the caller stores c.acc(s) again if i_end < n.  (Teams of one launch start a segment together, so a long
 // rotation's drift -- and with it the span of the key the L2s have to hold -- is bounded by the segment; see
-// kernels.hip::blind_rotate_segments.)
+// kernels.hip::blind_rotate_plan.)
 template <class F, int LOGN, int K, int G, int NS, class Ctx>
 TFHE_HD void blind_rotate_team_multi(const Ctx& c, const PbsParams& P, const u32* const* lwe /* NS x (n+1) */,
                                      const u32* const* tv /* NS x N, un-encoded */,
