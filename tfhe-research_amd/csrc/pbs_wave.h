@@ -398,9 +398,27 @@ TFHE_HD void external_product_team_multi(const Ctx& c, const PbsParams& P, const
   buffers_of_level(P.levels, ci);
   TopConsts<F, LT, G, false> itop;  // arrives during the first two passes of the first inverse transform
   if constexpr (TFHE_TOP_PREFETCH) itop.issue(c.twiddles_uniform());
+  // (TFHE_INVERSE_PAIR: one sample's two key parts go through the inverse transform half a step apart, each one's
+  // transposes covered by the other's register passes -- wave_ntt.h::ntt_inverse_pair)
+#ifndef TFHE_INVERSE_PAIR
+#define TFHE_INVERSE_PAIR 1
+#endif
+  // Measured where it is on (profiles/r03_kernel_ab.txt): the complex transform at 8 elements per lane (N = 1024), +0.9 %;
+  // at 4 elements per lane (N = 512) it is level, the prime fields' 16-element arrays spill with it.
+  constexpr bool PAIR = TFHE_INVERSE_PAIR && NS == 1 && PARTS == 2 && G == 1 && !SPLIT && NttShape<LT, G>::kPasses == 3 &&
+                        TFHE_TOP_PREFETCH && F::kLogShrink == 1 && E == 8;
   static_for<0, KEYS>([&](auto key_c) {
     constexpr int m = decltype(key_c)::value;
-    static_for<0, PARTS>([&](auto part_c) {
+    if constexpr (PAIR) {
+#pragma unroll
+      for (int r = 0; r < E; ++r) {
+        accum[0][m * PARTS][r] = F::before_inverse(accum[0][m * PARTS][r]);
+        accum[0][m * PARTS + 1][r] = F::before_inverse(accum[0][m * PARTS + 1][r]);
+      }
+      if constexpr (m == 0) itop.ready();
+      ntt_inverse_pair<F, LT, G>(ci[0], accum[0][m * PARTS], accum[0][m * PARTS + 1], itop);
+    }
+    static_for<0, PAIR ? 0 : PARTS>([&](auto part_c) {
       constexpr int q = m * PARTS + decltype(part_c)::value;
       // part q of every sample goes through the inverse transform together
       elem x[NS][E];

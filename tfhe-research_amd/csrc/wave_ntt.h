@@ -710,4 +710,30 @@ TFHE_HD void ntt_inverse(const Ctx& c, typename F::elem (&x)[NttShape<LOGN, G>::
   ntt_inverse<F, LOGN, G>(c, x, top);
 }
 
+// Two polynomials through ONE wave-private buffer, half a step apart: pass(a); T(a); pass(b); T(b); pass'(a); ...  A
+// transpose is eight stores and eight loads; the wave's LDS operations execute in order, so b's stores follow a's loads
+// into the same buffer without a wait, and the round trip of a's transpose is covered by b's register pass (and the
+// other way round) instead of by nothing.  Three-pass shapes with wave-local transposes only (G = 1).
+template <class F, int LOGN, int G, class Ctx, class Top>
+TFHE_HD void ntt_inverse_pair(const Ctx& c, typename F::elem (&a)[NttShape<LOGN, G>::kE],
+                              typename F::elem (&b)[NttShape<LOGN, G>::kE], const Top& top) {
+  using S = NttShape<LOGN, G>;
+  static_assert(G == 1 && S::kPasses == 3, "wave-local transposes, three passes");
+  constexpr bool PRE = PreloadsTwiddles<F>::value;
+  LowPassTwiddles<F, LOGN, G, S::kLo3, S::kLo2 - 1, S::kLo3, true, PRE> t3;
+  t3.load(c);
+  ntt_pass_inverse<F, LOGN, G, S::kLo3, S::kLo2 - 1, S::kLo3>(c, a, top, t3);
+  ntt_transpose<F, LOGN, G, S::kLo3, S::kLo2>(c, a);
+  ntt_pass_inverse<F, LOGN, G, S::kLo3, S::kLo2 - 1, S::kLo3>(c, b, top, t3);
+  LowPassTwiddles<F, LOGN, G, S::kLo2, S::kTBits - 1, S::kLo2, true, PRE> t2;
+  t2.load(c);
+  ntt_transpose<F, LOGN, G, S::kLo3, S::kLo2>(c, b);
+  ntt_pass_inverse<F, LOGN, G, S::kLo2, S::kTBits - 1, S::kLo2>(c, a, top, t2);
+  ntt_transpose<F, LOGN, G, S::kLo2, S::kLo1>(c, a);
+  ntt_pass_inverse<F, LOGN, G, S::kLo2, S::kTBits - 1, S::kLo2>(c, b, top, t2);
+  ntt_transpose<F, LOGN, G, S::kLo2, S::kLo1>(c, b);
+  ntt_pass_inverse<F, LOGN, G, S::kLo1, LOGN - 1, S::kTBits>(c, a, top, NoPassTwiddles{});
+  ntt_pass_inverse<F, LOGN, G, S::kLo1, LOGN - 1, S::kTBits>(c, b, top, NoPassTwiddles{});
+}
+
 }  // namespace tfhe
