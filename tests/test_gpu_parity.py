@@ -499,18 +499,26 @@ def test_cfg4_per_gpu_share_scrambled_copies(oracle):
         assert np.array_equal(base[b], oracle.bootstrap(p, lwe[b], bsk, ksk, tv)), b
 
 
-def test_torch_entry_points_follow_the_current_stream(oracle):
+@pytest.mark.parametrize("n,batch,streams", [(6, 512, 1), (16, 2304, 2)])
+def test_torch_entry_points_follow_the_current_stream(oracle, n, batch, streams):
     """The torch-tensor entry points are stream-ordered like torch ops: inputs produced on a side
     stream right before the call, output consumed on it right after, no host synchronisation and no
-    use_torch_stream() by the caller; then the same on the default stream."""
+    use_torch_stream() by the caller; then the same on the default stream.  The second case is a batch
+    larger than the chip over a key of two slices: its blind rotation forks onto the context's second
+    stream and joins again (kernels.hip::blind_rotate_plan) -- the producer must be waited for by both
+    streams and the consumer must wait for both."""
     import torch
-    p = oracle.Params(1, 10, 6, oracle.Decomposer(7, 3))
-    lwe, bsk, ksk, tv = oracle.synthetic_inputs(p, 512, cfg_index=12)
+    p = oracle.Params(1, 10, n, oracle.Decomposer(7, 3))
+    lwe, bsk, ksk, tv = oracle.synthetic_inputs(p, batch, cfg_index=12)
     m = pkg()
     dev = torch.device("cuda", 0)
     with m.Context(to_pkg_params(p)) as ctx:
         ctx.load_bootstrapping_key(bsk, ksk)
+        plan = ctx.blind_rotate_plan(batch)
+        assert plan["streams"] == streams and (plan["segments"] > 1) == (streams == 2), plan
         want = ctx.bootstrap(lwe, tv)
+        for b in (0, batch // 2 + 1, batch - 1):  # both halves of the batch against the oracle
+            assert np.array_equal(want[b], oracle.bootstrap(p, lwe[b], bsk, ksk, tv)), b
         src = torch.from_numpy(lwe.view(np.int32)).to(dev)
         tv_d = torch.from_numpy(tv.view(np.int32)).to(dev)
         torch.cuda.synchronize()
@@ -528,18 +536,21 @@ def test_torch_entry_points_follow_the_current_stream(oracle):
         ctx.set_stream(None)
 
 
-def test_device_entry_points_are_graph_capturable(oracle):
+@pytest.mark.parametrize("n,batch", [(6, 16), (16, 2304)])
+def test_device_entry_points_are_graph_capturable(oracle, n, batch):
     """The `_device` entry points promise no allocation and no synchronisation once the workspace is
     reserved: capture a whole bootstrap (blind rotation + key switch) into a HIP graph on a torch
-    stream, replay it on new inputs, and compare with the eager result and the oracle."""
+    stream, replay it on new inputs, and compare with the eager result and the oracle.  Second case: a
+    batch whose eager plan uses the context's second stream -- inside a capture the launches stay on the
+    captured stream (segments, one stream), same bits."""
     import torch
-    p = oracle.Params(1, 10, 6, oracle.Decomposer(7, 3))
-    lwe, bsk, ksk, tv = oracle.synthetic_inputs(p, 16, cfg_index=11)
+    p = oracle.Params(1, 10, n, oracle.Decomposer(7, 3))
+    lwe, bsk, ksk, tv = oracle.synthetic_inputs(p, batch, cfg_index=11)
     m = pkg()
     dev = torch.device("cuda", 0)
     with m.Context(to_pkg_params(p)) as ctx:
         ctx.load_bootstrapping_key(bsk, ksk)
-        ctx.reserve(16)
+        ctx.reserve(batch)
         lwe_d = torch.from_numpy(lwe.view(np.int32).copy()).to(dev)
         tv_d = torch.from_numpy(tv.view(np.int32).copy()).to(dev)
         out_d = torch.empty_like(lwe_d)
