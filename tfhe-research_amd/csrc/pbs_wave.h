@@ -259,11 +259,13 @@ TFHE_HD void external_product_team_multi(const Ctx& c, const PbsParams& P, const
 #define TFHE_KEY_BUFFERS 2
 #endif
   // staging buffers: chunk i + NB - 1 is fetched while chunk i is consumed.  Two everywhere (three and four measured
-  // nothing at one sample per team, profiles/r02_kernel_ab.txt) except the half-size chunks of two samples per team with
-  // one wave per polynomial: there a third buffer keeps the same bytes in flight as before (cfg3: 68.6 -> 63.8 ms; a
-  // fourth 65.9; at N = 2048 the third costs 31 more spilled registers: 57.3 -> 63.2 ms)
+  // nothing at one sample per team, profiles/r02_kernel_ab.txt).  The half-size chunks of two samples per team with one
+  // wave per polynomial had a third while the key came from beyond the L2s (cfg3 in one launch over the whole key:
+  // 68.6 -> 63.8 ms; a fourth 65.9; at N = 2048 the third costs 31 more spilled registers: 57.3 -> 63.2 ms); with the key
+  // blocked for the L2s (kernels.hip::blind_rotate_plan) two are enough and spill nothing: cfg3 53.6 -> 52.8 ms
+  // (three: 10 spilled registers, four: 54.1 ms; profiles/r03_kernel_ab.txt)
 #ifndef TFHE_KEY_BUFFERS_NS
-#define TFHE_KEY_BUFFERS_NS 3
+#define TFHE_KEY_BUFFERS_NS 2
 #endif
   constexpr int NB = (NS > 1 && G == 1) ? TFHE_KEY_BUFFERS_NS : TFHE_KEY_BUFFERS;
   elem kbuf[NB][CH];
