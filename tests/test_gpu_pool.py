@@ -71,6 +71,29 @@ def test_pool_equals_single_context_on_a_ragged_full_size_batch(oracle, backend)
         assert np.array_equal(got[b], oracle.bootstrap(p, lwe[b], bsk, ksk, tvs[b])), b
 
 
+def test_pool_members_with_two_stream_plans_share_a_device(oracle):
+    """Two members on one device, each with a shard larger than the chip over a key of two slices: every member's blind
+    rotation forks onto its own second stream (kernels.hip::blind_rotate_plan) while the other member's two streams run
+    beside it -- four streams on the card, one host thread per member.  Every word equals the single-context run; rows of
+    both shards (and both halves of each) against the oracle."""
+    m = pkg()
+    p = oracle.Params(1, 10, 16, oracle.Decomposer(7, 3))
+    batch = 4608  # 2,304 per member > the 1,024 samples the chip rotates at once
+    lwe, bsk, ksk, tv = oracle.synthetic_inputs(p, batch, cfg_index=21)
+    with m.Context(to_pkg_params(p)) as ctx:
+        ctx.load_bootstrapping_key(bsk, ksk)
+        plan = ctx.blind_rotate_plan(batch // 2)
+        assert plan["streams"] == 2 and plan["segments"] == 2, plan
+        want = ctx.bootstrap(lwe, tv)
+    with m.Pool(to_pkg_params(p), [0, 0]) as pool:
+        pool.load_bootstrapping_key(bsk, ksk)
+        got = pool.bootstrap(lwe, tv)
+        again = pool.bootstrap(lwe, tv)
+    assert np.array_equal(got, want) and np.array_equal(again, want)
+    for b in (0, 1151, 1153, 2303, 2304, 3457, 4607):
+        assert np.array_equal(got[b], oracle.bootstrap(p, lwe[b], bsk, ksk, tv)), b
+
+
 def test_pool_device_shards_and_device_key(oracle):
     """keys handed over as device tensors (member 0's device), shards resident on the members' devices, enqueue-only
     entry point + tfhe_pool_synchronize; aligned decomposer set through the pool so that the rotation depends on the key"""
