@@ -269,12 +269,30 @@ TFHE_HD void external_product_team_multi(const Ctx& c, const PbsParams& P, const
 #endif
   constexpr int NB = (NS > 1 && G == 1) ? TFHE_KEY_BUFFERS_NS : TFHE_KEY_BUFFERS;
   elem kbuf[NB][CH];
+  // OWN (TFHE_OWN_FIRST): a wave starts every level's multiply-accumulate with the digit spectrum it has just computed
+  // itself -- straight from its registers, BEFORE the team barrier that makes the other groups' spectra visible -- and takes
+  // the source polynomials in the order me, me + 1, ... (mod k + 1): one spectrum fewer to read back from LDS per level, and
+  // a (k+1)-th of the products under the barrier's wait.  (The order of the exact integer sum changes, its value does not.)
+  // The complex transform with one sample per team and one wave per polynomial: cfg2 31.9 -> 30.3 ms (reading the own
+  // spectrum back from LDS, i.e. the barrier overlap alone: 30.8), cfg1 10.6 -> 10.5.  Not elsewhere: with two samples per
+  // team the kept spectra spill (cfg3 52.7 -> 55.6 ms; through LDS: level; cfg5 51 -> 55-66 ms), the prime fields'
+  // 16-element arrays spill or gain nothing (+-1 %) -- profiles/r03_kernel_ab.txt.
+#ifndef TFHE_OWN_FIRST
+#define TFHE_OWN_FIRST 1
+#endif
+  constexpr bool OWN = TFHE_OWN_FIRST && F::kLogShrink == 1 && NS == 1 && G == 1 && !SPLIT;
+  constexpr bool OWN_REGS = OWN;
+  auto source_of = [&](int sp) -> int {  // the source polynomial behind chunk position sp
+    if (!OWN) return sp;
+    const int at = me + sp;
+    return at > K ? at - (K + 1) : at;
+  };
   // piece of the key a chunk index names: tile (source polynomial, accumulator) and offset inside it
   auto load_chunk = [&](u32 level, auto ci_c, int buf) {
     constexpr int ci = decltype(ci_c)::value;
     constexpr int PIECES = E / CH;
     constexpr int q = ci % ACCS, r0 = ((ci / ACCS) % PIECES) * CH, src_poly = ci / (ACCS * PIECES);
-    const elem* tile = tile_ptr(level, src_poly, q);
+    const elem* tile = tile_ptr(level, source_of(src_poly), q);
 #pragma unroll
     for (int r = 0; r < CH; ++r)
       kbuf[buf][r] = tile[TFHE_PROBE_HOT_KEY ? (lane & 63) + r : spectrum_slot<LT, G, (int)sizeof(elem)>(lane, r0 + r)];
@@ -303,6 +321,7 @@ TFHE_HD void external_product_team_multi(const Ctx& c, const PbsParams& P, const
 #endif
     constexpr int FS = (NS > 1 && !TFHE_NS_LOCKSTEP_FORWARD) ? 1 : NS;  // samples per forward transform call
     const u32 carry_width = (t == 0) ? 0u : 1u;  // wave-uniform: the lowest kept limb has no carry-in
+    elem own[OWN_REGS ? NS : 1][OWN_REGS ? E : 1];  // OWN_REGS: my digit spectrum of this level, as published
 #pragma unroll
     for (int s0 = 0; s0 < NS; s0 += FS) {
       elem work[FS][E];
@@ -352,9 +371,13 @@ TFHE_HD void external_product_team_multi(const Ctx& c, const PbsParams& P, const
         elem* mine = cf[s].scratch();
 #pragma unroll
         for (int r = 0; r < E; ++r) mine[exchange_slot<LT, G>(lane, r)] = work[s][r];
+        if constexpr (OWN_REGS) {
+#pragma unroll
+          for (int r = 0; r < E; ++r) own[s0 + s][r] = work[s][r];
+        }
       }
     }
-    c.team_sync();
+    if constexpr (!OWN) c.team_sync();
     // chunk order: source polynomial sp, then the CH-register piece of its spectrum, then the
     // accumulator (key, key part) -- so that a piece of a digit spectrum is read from LDS once and
     // used for every key and part, and a key chunk is fetched once and used for every sample
@@ -364,15 +387,23 @@ TFHE_HD void external_product_team_multi(const Ctx& c, const PbsParams& P, const
       constexpr int PIECES = E / CH;
       constexpr int q = ci % ACCS, r0 = ((ci / ACCS) % PIECES) * CH, sp = ci / (ACCS * PIECES);
       constexpr int cur = ci % NB;
+      if constexpr (OWN && ci == ACCS * PIECES) c.team_sync();  // my own spectrum is done with: now the others'
       if constexpr (ci + NB - 1 < CHUNKS) load_chunk(level, IntC<ci + NB - 1>{}, (ci + NB - 1) % NB);
       // (TFHE_PROBE_NO_EXCHANGE_READS: timing probe, WRONG BITS -- the digit spectra are not read back from LDS.)
 #ifndef TFHE_PROBE_NO_EXCHANGE_READS
 #define TFHE_PROBE_NO_EXCHANGE_READS 0
 #endif
-      if constexpr (q == 0 && !(TFHE_PROBE_NO_EXCHANGE_READS)) {
+      if constexpr (OWN_REGS && sp == 0) {
+        if constexpr (q == 0) {
+#pragma unroll
+          for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int r = 0; r < CH; ++r) d[s][r] = own[s][r0 + r];
+        }
+      } else if constexpr (q == 0 && !(TFHE_PROBE_NO_EXCHANGE_READS)) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-          const elem* spec = cl[s].scratch_of(sp);
+          const elem* spec = cl[s].scratch_of(source_of(sp));
 #pragma unroll
           for (int r = 0; r < CH; ++r) d[s][r] = spec[exchange_slot<LT, G>(lane, r0 + r)];
         }
