@@ -282,6 +282,15 @@ TFHE_HD void external_product_team_multi(const Ctx& c, const PbsParams& P, const
 #endif
   constexpr bool OWN = TFHE_OWN_FIRST && F::kLogShrink == 1 && NS == 1 && G == 1 && !SPLIT;
   constexpr bool OWN_REGS = OWN;
+  // LATE (TFHE_LATE_BARRIER): the barrier that ends a level -- everyone is done reading the spectra before a buffer is
+  // written again -- moves from behind the multiply-accumulate to just in front of the NEXT transform's first store into
+  // the buffer (its first transpose; the inverse transform's after the last level): decomposition and the first register
+  // pass touch no buffer and run under the barrier's wait.  Same shapes as OWN: cfg2 30.15 -> 28.9 ms, cfg1 10.5 -> 10.45;
+  // with two samples per team level (cfg3 51.4 -> 51.3 ms) or worse (cfg5 51.0 -> 54.2 ms, 9 more spilled registers).
+#ifndef TFHE_LATE_BARRIER
+#define TFHE_LATE_BARRIER 1
+#endif
+  constexpr bool LATE = TFHE_LATE_BARRIER && TFHE_TOP_PREFETCH && OWN;
   auto source_of = [&](int sp) -> int {  // the source polynomial behind chunk position sp
     if (!OWN) return sp;
     const int at = me + sp;
@@ -354,7 +363,10 @@ TFHE_HD void external_product_team_multi(const Ctx& c, const PbsParams& P, const
       Ctx cf[FS];
 #pragma unroll
       for (int s = 0; s < FS; ++s) cf[s] = cl[s0 + s];
-      if constexpr (TFHE_TOP_PREFETCH) {
+      if constexpr (LATE) {
+        // (level 0 follows the previous product's inverse transforms, which use a wave's own buffer only: no barrier owed)
+        ntt_forward_multi<F, LT, G, true, true>(cf, work, ftop, [&]() { if (t > 0 && !two && s0 == 0) c.team_sync(); });
+      } else if constexpr (TFHE_TOP_PREFETCH) {
         ntt_forward_multi<F, LT, G, true, true>(cf, work, ftop);
       } else {
         const TopFromTable<elem> top{c.twiddles_uniform(), 1 << LT};
@@ -424,7 +436,7 @@ TFHE_HD void external_product_team_multi(const Ctx& c, const PbsParams& P, const
             accum[s][q][r0 + r] = F::mul_add(d[s][r], kbuf[cur][r], accum[s][q][r0 + r]);
         }
     });
-    if (!two) c.team_sync();  // everyone is done reading before the next transform reuses the buffer
+    if (!two && !LATE) c.team_sync();  // everyone is done reading before the next transform reuses the buffer
   }
 
   Ctx ci[NS];
@@ -449,7 +461,10 @@ TFHE_HD void external_product_team_multi(const Ctx& c, const PbsParams& P, const
         accum[0][m * PARTS + 1][r] = F::before_inverse(accum[0][m * PARTS + 1][r]);
       }
       if constexpr (m == 0) itop.ready();
-      ntt_inverse_pair<F, LT, G>(ci[0], accum[0][m * PARTS], accum[0][m * PARTS + 1], itop);
+      if constexpr (LATE && m == 0)
+        ntt_inverse_pair<F, LT, G>(ci[0], accum[0][m * PARTS], accum[0][m * PARTS + 1], itop, [&]() { if (!two) c.team_sync(); });
+      else
+        ntt_inverse_pair<F, LT, G>(ci[0], accum[0][m * PARTS], accum[0][m * PARTS + 1], itop);
     }
     static_for<0, PAIR ? 0 : PARTS>([&](auto part_c) {
       constexpr int q = m * PARTS + decltype(part_c)::value;
@@ -461,7 +476,14 @@ TFHE_HD void external_product_team_multi(const Ctx& c, const PbsParams& P, const
         for (int r = 0; r < E; ++r)
           x[s][r] = SPLIT ? F::mac_finish(accum[s][q][r], accum_lo[SPLIT ? q : 0][SPLIT ? r : 0])
                           : F::before_inverse(accum[s][q][r]);
-      if constexpr (TFHE_TOP_PREFETCH) {
+      if constexpr (LATE) {
+        if constexpr (q == 0) {
+          itop.ready();
+          ntt_inverse_multi<F, LT, G>(ci, x, itop, [&]() { if (!two) c.team_sync(); });  // the last level's barrier
+        } else {
+          ntt_inverse_multi<F, LT, G>(ci, x, itop);
+        }
+      } else if constexpr (TFHE_TOP_PREFETCH) {
         if constexpr (q == 0) itop.ready();  // nothing else is in flight here: the wait is for the block alone
         ntt_inverse_multi<F, LT, G>(ci, x, itop);
       } else {

@@ -626,14 +626,22 @@ struct LowPassTwiddles<F, LOGN, G, LO, BHI, BLO, INVERSE, false> : NoPassTwiddle
   TFHE_HD void load(const Ctx&) {}
 };
 
-template <class F, int LOGN, int G, bool SMALL_INPUT = false, bool AFTER_BARRIER = false, int NS, class Ctx, class Top>
-TFHE_HD void ntt_forward_multi(const Ctx (&c)[NS], typename F::elem (&x)[NS][NttShape<LOGN, G>::kE], const Top& top) {
+// before_first_store(): called once, after the first register pass and before the first store into the buffer -- the
+// place for a barrier that only has to precede the buffer's reuse (pbs_wave.h, TFHE_LATE_BARRIER)
+struct NothingBefore {
+  TFHE_HD void operator()() const {}
+};
+template <class F, int LOGN, int G, bool SMALL_INPUT = false, bool AFTER_BARRIER = false, int NS, class Ctx, class Top,
+          class Before = NothingBefore>
+TFHE_HD void ntt_forward_multi(const Ctx (&c)[NS], typename F::elem (&x)[NS][NttShape<LOGN, G>::kE], const Top& top,
+                               const Before& before_first_store = Before{}) {
   using S = NttShape<LOGN, G>;
   constexpr bool PRE = PreloadsTwiddles<F>::value;
   ntt_pass_forward_each<F, LOGN, G, S::kLo1, LOGN - 1, S::kTBits, SMALL_INPUT>(c, x, top, NoPassTwiddles{});
   // every low pass's twiddles are read before the transpose in front of it (PassTwiddles)
   LowPassTwiddles<F, LOGN, G, S::kLo2, S::kTBits - 1, S::kLo2, false, PRE> t2;
   t2.load(c[0]);
+  before_first_store();
   ntt_transpose_multi<F, LOGN, G, S::kLo1, S::kLo2, AFTER_BARRIER>(c, x);
   ntt_pass_forward_each<F, LOGN, G, S::kLo2, S::kTBits - 1, S::kLo2, false>(c, x, top, t2);
   LowPassTwiddles<F, LOGN, G, S::kLo3, S::kLo2 - 1, S::kLo3, false, PRE> t3;
@@ -671,8 +679,9 @@ TFHE_HD void ntt_forward(const Ctx& c, typename F::elem (&x)[NttShape<LOGN, G>::
 // A prefetched `top` must be ready() before the call.
 // (the first pass's twiddles are read on entry -- nothing to hide them behind but the caller's last
 // instructions --, every later low pass's before the transpose in front of it)
-template <class F, int LOGN, int G, int NS, class Ctx, class Top>
-TFHE_HD void ntt_inverse_multi(const Ctx (&c)[NS], typename F::elem (&x)[NS][NttShape<LOGN, G>::kE], const Top& top) {
+template <class F, int LOGN, int G, int NS, class Ctx, class Top, class Before = NothingBefore>
+TFHE_HD void ntt_inverse_multi(const Ctx (&c)[NS], typename F::elem (&x)[NS][NttShape<LOGN, G>::kE], const Top& top,
+                               const Before& before_first_store = Before{}) {
   using S = NttShape<LOGN, G>;
   constexpr bool PRE = PreloadsTwiddles<F>::value;
   if constexpr (S::kPasses == 5) {
@@ -683,15 +692,22 @@ TFHE_HD void ntt_inverse_multi(const Ctx (&c)[NS], typename F::elem (&x)[NS][Ntt
   if constexpr (S::kPasses >= 4) {
     LowPassTwiddles<F, LOGN, G, S::kLo4, S::kLo3 - 1, S::kLo4, true, PRE> t4;
     t4.load(c[0]);
-    if constexpr (S::kPasses == 5) ntt_transpose_multi<F, LOGN, G, S::kLo5, S::kLo4>(c, x);
+    if constexpr (S::kPasses == 5) {
+      before_first_store();
+      ntt_transpose_multi<F, LOGN, G, S::kLo5, S::kLo4>(c, x);
+    }
     ntt_pass_inverse_each<F, LOGN, G, S::kLo4, S::kLo3 - 1, S::kLo4>(c, x, top, t4);
   }
   LowPassTwiddles<F, LOGN, G, S::kLo3, S::kLo2 - 1, S::kLo3, true, PRE> t3;
   t3.load(c[0]);
-  if constexpr (S::kPasses >= 4) ntt_transpose_multi<F, LOGN, G, S::kLo4, S::kLo3>(c, x);
+  if constexpr (S::kPasses >= 4) {
+    if constexpr (S::kPasses == 4) before_first_store();
+    ntt_transpose_multi<F, LOGN, G, S::kLo4, S::kLo3>(c, x);
+  }
   ntt_pass_inverse_each<F, LOGN, G, S::kLo3, S::kLo2 - 1, S::kLo3>(c, x, top, t3);
   LowPassTwiddles<F, LOGN, G, S::kLo2, S::kTBits - 1, S::kLo2, true, PRE> t2;
   t2.load(c[0]);
+  if constexpr (S::kPasses == 3) before_first_store();
   ntt_transpose_multi<F, LOGN, G, S::kLo3, S::kLo2>(c, x);
   ntt_pass_inverse_each<F, LOGN, G, S::kLo2, S::kTBits - 1, S::kLo2>(c, x, top, t2);
   ntt_transpose_multi<F, LOGN, G, S::kLo2, S::kLo1>(c, x);
@@ -714,15 +730,17 @@ TFHE_HD void ntt_inverse(const Ctx& c, typename F::elem (&x)[NttShape<LOGN, G>::
 // transpose is eight stores and eight loads; the wave's LDS operations execute in order, so b's stores follow a's loads
 // into the same buffer without a wait, and the round trip of a's transpose is covered by b's register pass (and the
 // other way round) instead of by nothing.  Three-pass shapes with wave-local transposes only (G = 1).
-template <class F, int LOGN, int G, class Ctx, class Top>
+template <class F, int LOGN, int G, class Ctx, class Top, class Before = NothingBefore>
 TFHE_HD void ntt_inverse_pair(const Ctx& c, typename F::elem (&a)[NttShape<LOGN, G>::kE],
-                              typename F::elem (&b)[NttShape<LOGN, G>::kE], const Top& top) {
+                              typename F::elem (&b)[NttShape<LOGN, G>::kE], const Top& top,
+                              const Before& before_first_store = Before{}) {
   using S = NttShape<LOGN, G>;
   static_assert(G == 1 && S::kPasses == 3, "wave-local transposes, three passes");
   constexpr bool PRE = PreloadsTwiddles<F>::value;
   LowPassTwiddles<F, LOGN, G, S::kLo3, S::kLo2 - 1, S::kLo3, true, PRE> t3;
   t3.load(c);
   ntt_pass_inverse<F, LOGN, G, S::kLo3, S::kLo2 - 1, S::kLo3>(c, a, top, t3);
+  before_first_store();
   ntt_transpose<F, LOGN, G, S::kLo3, S::kLo2>(c, a);
   ntt_pass_inverse<F, LOGN, G, S::kLo3, S::kLo2 - 1, S::kLo3>(c, b, top, t3);
   LowPassTwiddles<F, LOGN, G, S::kLo2, S::kTBits - 1, S::kLo2, true, PRE> t2;
