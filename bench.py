@@ -560,7 +560,7 @@ def main():
             "algorithmic_bytes_per_launch": algo_bytes,
             "external_products_per_s": ext_products / (br_avg * 1e-3),
             "key_switch_kernel_ms": ks_avg,
-            "note": ("fp64-fft: VALU, the LDS store path and the key stream from L2 are within 30 % of each other (DESIGN.md 2); "
+            "note": ("fp64-fft: SIMD issue -- VALU instructions about three quarters of the time, the LDS traffic of the transposes most of the rest (DESIGN.md 2); "
                      if backend_name == "fp64-fft" else "VALU-issue bound by design (SURVEY 8d); ")
                     + "the key is shared by the batch and stays in L2/Infinity Cache; HBM fraction reported as the metric asks",
         },
