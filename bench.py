@@ -71,17 +71,21 @@ def measure_hbm_copy_gbs(torch, dev, mib: int = 1024, reps: int = 10, ctx=None) 
 
 
 def kernel_source_hash() -> str:
-    """sha256 over the CODE of the sources the device library is built from (csrc/*, include/tfhe_hip.h, the build
-    recipe), first 16 hex digits: identifies the kernels a PMC record was measured on.  Comments and white space do not
-    count (a reworded comment must not invalidate a measurement; any token that reaches the compiler does).  (Not the .so
-    itself: hipcc output embeds build paths, and the box that collects counters builds nothing -- it runs the library
-    this tree built.)"""
+    """sha256 over the CODE of the sources the DEVICE code is built from (csrc/kernels.hip and the csrc headers it
+    includes, the build recipe), first 16 hex digits: identifies the kernels a PMC record was measured on.  Host-only
+    sources (capi.cpp, pool.cpp, context.h, the C ABI header) do not count -- a host edit leaves a kernel measurement
+    valid -- and neither do comments and white space (a reworded comment must not invalidate a measurement; any token
+    that reaches the device compiler does).  Only regular files of the explicit list are read: an editor backup or a
+    directory under csrc/ changes nothing.  (Not the .so itself: hipcc output embeds build paths, and the box that
+    collects counters builds nothing -- it runs the library this tree built.)"""
     import hashlib
     import re
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "tfhe-research_amd", "csrc")
-    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc))
-    files += [os.path.join(ROOT, "include", "tfhe_hip.h"), os.path.join(ROOT, "tfhe-research_amd", "build.py")]
+    host_only = {"context.h"}
+    names = ["kernels.hip"] + sorted(f for f in os.listdir(csrc) if f.endswith(".h") and f not in host_only)
+    files = [os.path.join(csrc, f) for f in names if os.path.isfile(os.path.join(csrc, f))]
+    files.append(os.path.join(ROOT, "tfhe-research_amd", "build.py"))
     for f in files:
         with open(f, "r", errors="replace") as fh:
             text = fh.read()
@@ -89,7 +93,8 @@ def kernel_source_hash() -> str:
             text = re.sub(r"#[^\n]*", "", text)
         else:
             text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)   # block comments
-            text = re.sub(r"//[^\n]*", "", text)                # line comments (no string literal of these sources holds "//")
+            # line comments; a "//" inside a string literal stays (the literal is matched first and kept)
+            text = re.sub(r'"(?:\\.|[^"\\\n])*"|//[^\n]*', lambda m: m.group(0) if m.group(0).startswith('"') else "", text)
         text = re.sub(r"\s+", " ", text).strip()
         h.update(os.path.basename(f).encode() + b"\0" + text.encode() + b"\0")
     return h.hexdigest()[:16]
@@ -124,49 +129,125 @@ WORKLOADS = {
     "cfg4": (1, 10, 630, (7, 3), (4, 5), 2, 1 << 17),
 }
 CPU_BASELINE_PBS = 3        # >= 3 PBS on one thread (the reference is single-threaded)
-CPU_BASELINE_THREADS = 16   # the multi-thread leg: one round of independent ciphertexts on 16 threads (NOT all cores)
+CPU_ALIGNED_CHECK_ROWS = 16  # rows of the aligned-decomposer leg the oracle re-computes (the leg whose digits are non-zero)
 
 
-def cpu_baseline(workload: str, budget_s: float):
-    """Time the oracle's literal path (Toeplitz matrix + mat-vec, as the reference does) on a bounded
-    sample: CPU_BASELINE_PBS whole bootstraps of the same parameter set on a single thread (the
-    reference is single-threaded), stopping early once `budget_s` is spent; then one round of
-    independent ciphertexts on up to CPU_BASELINE_THREADS host threads.  Kept short on purpose: the
-    GPU part of a default run is a second or two, and a CPU leg of half a minute would be nearly
-    all the driver's activity sampler ever sees."""
+def usable_cores() -> dict:
+    """Host cores this process may really use: the scheduler affinity, capped by the cgroup CPU quota when the box
+    sets one (a GPU box hands a one-GPU job a share of its host, whatever os.cpu_count() says)."""
+    logical = os.cpu_count() or 1
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        affinity = logical
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:          # cgroup v2: "<quota|max> <period>"
+            q, period = f.read().split()
+            if q != "max":
+                quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, period = float(f.read()), float(g.read())
+                if q > 0:
+                    quota = q / period
+        except (OSError, ValueError):
+            pass
+    usable = affinity if quota is None else max(1, min(affinity, int(quota + 0.5)))
+    return {"logical": logical, "affinity": affinity, "cgroup_quota": quota, "usable": usable}
+
+
+def spaced_rows(batch: int, count: int):
+    """`count` distinct row indices of a batch, first and last included, evenly spaced."""
+    count = max(1, min(count, batch))
+    if count == 1:
+        return [0]
+    return sorted({round(i * (batch - 1) / (count - 1)) for i in range(count)})
+
+
+def cpu_legs(workload: str, budget_s: float, host: dict):
+    """The CPU side of a run, on rows OF THE TIMED BATCH (host: numpy copies of `lwe` rows, bsk, ksk, tv and of the rows
+    the GPU wrote for them), so that the baseline also checks the bits that were timed:
+
+      1. `single`: CPU_BASELINE_PBS whole bootstraps, literal Toeplitz path (utils.rs:113-160, as the reference does),
+         one thread (the reference is single-threaded) -> cpu_baseline.value; every row compared with the GPU's.
+      2. `cores_all`: one bootstrap per usable host core ("an all-cores run, nproc stated"), same path, one
+         round of independent ciphertexts of the timed batch (ctypes releases the GIL) -> cpu_baseline.cores_all; every
+         row compared.
+      3. the aligned-decomposer leg's rows (the cfg2 timing in which digits are non-zero and the result depends on the
+         key), up to CPU_ALIGNED_CHECK_ROWS, re-computed with the oracle's aligned decomposer (schoolbook product: this
+         leg is a check, not a timing) and compared.
+
+    -> (cpu_baseline dict, verified dict).  Kept short on purpose (about 25 s of wall clock at cfg2)."""
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as orc
     orc.build()
     k, logn, n, pbs, ks, log_p, _ = WORKLOADS[workload]
     p = orc.Params(k, logn, n, orc.Decomposer(*pbs), orc.Decomposer(*ks), log_p=log_p)
-    lwe, bsk, ksk, tv = orc.synthetic_inputs(p, CPU_BASELINE_PBS, cfg_index=2)
+    bsk, ksk, tv = host["bsk"], host["ksk"], host["tv"]
+    idx, lwe, gpu = host["rows"], host["lwe_rows"], host["gpu_rows"]
+    pos = {r: i for i, r in enumerate(idx)}
+    cores = usable_cores()
+    mismatches = []
+
+    def check(row, want, leg):
+        if not np.array_equal(want, gpu[pos[row]]):
+            mismatches.append({"row": int(row), "leg": leg, "words_differing": int(np.count_nonzero(want != gpu[pos[row]]))})
+
     orc.set_poly_mul_mode(0)
+    single_rows = host["single_rows"]
     done, t0 = 0, time.perf_counter()
-    while done < lwe.shape[0]:
-        orc.bootstrap(p, lwe[done], bsk, ksk, tv)
+    for r in single_rows:
+        check(r, orc.bootstrap(p, lwe[pos[r]], bsk, ksk, tv), "single")
         done += 1
         if time.perf_counter() - t0 >= budget_s:
             break
     dt = time.perf_counter() - t0
-    result = {
+    baseline = {
         "value": done / dt, "unit": "PBS/s", "cores": 1, "kind": "port",
-        "sample": f"{done} full bootstraps of {workload} (literal Toeplitz path, gcc -O2, 1 thread) in {dt:.1f} s",
-        "host_cores_available": os.cpu_count(),
+        "sample": f"rows {single_rows[:done]} of the timed batch: {done} full bootstraps of {workload} (literal Toeplitz path, "
+                  f"gcc -O2, 1 thread) in {dt:.1f} s",
+        "host_cores_available": cores["logical"], "host_cores": cores,
     }
-    # the same port on several host cores (independent ciphertexts, one per thread; ctypes releases
-    # the GIL): the fair throughput comparison, reported beside the single-thread number, not instead
-    threads = min(os.cpu_count() or 1, CPU_BASELINE_THREADS)
+    checked = done
+    threads = min(cores["usable"], len(idx))
     if threads > 1 and budget_s > 0:
-        from concurrent.futures import ThreadPoolExecutor
-        lwe_many = np.tile(lwe, (threads // lwe.shape[0] + 1, 1))[:threads]
+        rows_all = [idx[i] for i in spaced_rows(len(idx), threads)]
         t1 = time.perf_counter()
         with ThreadPoolExecutor(threads) as pool:
-            list(pool.map(lambda row: orc.bootstrap(p, row, bsk, ksk, tv), lwe_many))
+            wants = list(pool.map(lambda r: orc.bootstrap(p, lwe[pos[r]], bsk, ksk, tv), rows_all))
         dt_all = time.perf_counter() - t1
-        result[f"cores_{threads}"] = {"value": threads / dt_all, "unit": "PBS/s", "cores": threads,
-                                      "sample": f"{threads} bootstraps on {threads} threads in {dt_all:.1f} s "
-                                                f"(a capped leg: the host has {os.cpu_count()} cores)"}
+        for r, w in zip(rows_all, wants):
+            check(r, w, "cores_all")
+        checked += len(rows_all)
+        baseline["cores_all"] = {
+            "value": len(rows_all) / dt_all, "unit": "PBS/s", "cores": threads,
+            "sample": f"{len(rows_all)} bootstraps of rows of the timed batch, one per thread on {threads} threads "
+                      f"(= the host cores this process may use: affinity {cores['affinity']}, cgroup quota {cores['cgroup_quota']}, "
+                      f"{cores['logical']} logical) in {dt_all:.1f} s"}
+    verified = {"rows": checked, "bit_exact": not mismatches,
+                "what": f"oracle (literal Toeplitz path) on rows of the timed batch, every word of {checked} output rows "
+                        "against what the timed steps left in HBM"}
+    aligned = host.get("aligned_gpu_rows")
+    if aligned is not None:
+        orc.set_poly_mul_mode(1)
+        rows_al = [idx[i] for i in spaced_rows(len(idx), min(CPU_ALIGNED_CHECK_ROWS, max(threads, 3)))]
+        bad = []
+        with orc.decomposer_aligned(True):
+            with ThreadPoolExecutor(max(1, min(threads, len(rows_al)))) as pool:
+                wants = list(pool.map(lambda r: orc.bootstrap(p, lwe[pos[r]], bsk, ksk, tv), rows_al))
+        for r, w in zip(rows_al, wants):
+            if not np.array_equal(w, aligned[pos[r]]):
+                bad.append(int(r))
+        verified["aligned_decomposer"] = {"rows": len(rows_al), "bit_exact": not bad, "rows_differing": bad}
+        if bad:
+            mismatches.append({"leg": "aligned_decomposer", "rows": bad})
+    if mismatches:
+        verified["mismatches"] = mismatches[:8]
+        verified["bit_exact"] = False
     orc.set_poly_mul_mode(1)
-    return result
+    return baseline, verified
 
 
 def bench_external_product(args, pkg, params, batch, dev, rand_words, world, rank, local_rank, backend):
@@ -276,6 +357,63 @@ def bench_external_product(args, pkg, params, batch, dev, rand_words, world, ran
         dist.destroy_process_group()
 
 
+def bench_batch_sweep(args, pkg, dev, local_rank, backend):
+    """The reference's own call shape (bootstrap() takes ONE ciphertext, and()/or() one pair: bootstrapping.rs:58-65,
+    boolean.rs:9-37) and everything between it and the headline batch: for each workload and batch size
+      latency_ms   one synchronised call (enqueue -> results complete), median of `reps` calls: what a caller that needs
+                   the result before it goes on (a dependent gate) waits;
+      pbs_per_s    `reps` calls enqueued back to back, one synchronisation: the rate of independent small batches;
+      plan         how the blind rotation of that batch goes out (kernel shape, launches, streams).
+    One JSON line: {"metric": "batch_sweep", "rows": [...]}."""
+    import torch
+    rows = []
+    workloads = [w for w in args.sweep_workloads.split(",") if w]
+    for wl in workloads:
+        k, logn, n, pbs, ks, log_p, _ = WORKLOADS[wl]
+        params = pkg.TfheParams(k, logn, n, pkg.DecomposerParams(*pbs), pkg.DecomposerParams(*ks), log_p=log_p)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(0x74666865)
+        rw = lambda *shape: torch.randint(-(1 << 31), (1 << 31) - 1, shape, dtype=torch.int32, device=dev, generator=gen)
+        sizes = [int(b) for b in args.sweep_batches.split(",")]
+        lwe_all = rw(max(sizes), n + 1)
+        tv = torch.from_numpy(pkg.construct_identity_test_vector(params).astype(np.int32)).to(dev)
+        ctx = pkg.Context(params, device=local_rank, backend=backend)
+        ctx.use_torch_stream()
+        ctx.load_bootstrapping_key(rw(*params.bsk_shape()), rw(*params.ksk_shape()))
+        if pbs[0] * (32 // pbs[0]) != 32:
+            ctx.set_decomposer_alignment(True)   # cfg2: the data-dependent timing (the literal decomposer multiplies zeros)
+        ctx.reserve(max(sizes))
+        ctx.set_timing(True)
+        for b in sizes:
+            lwe = lwe_all[:b]
+            out = torch.empty_like(lwe)
+            reps = max(10, min(200, 4096 // b))
+            for _ in range(max(3, reps // 4)):
+                ctx.bootstrap(lwe, tv, out=out)
+            torch.cuda.synchronize()
+            lat = []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                ctx.bootstrap(lwe, tv, out=out)
+                torch.cuda.synchronize()
+                lat.append(time.perf_counter() - t0)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                ctx.bootstrap(lwe, tv, out=out)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            br, ksm = ctx.kernel_ms_ago(0)
+            rows.append({"workload": wl, "batch": b, "latency_ms": float(np.median(lat)) * 1e3,
+                         "latency_ms_min": float(np.min(lat)) * 1e3, "pbs_per_s": b * reps / dt,
+                         "blind_rotate_ms": br, "key_switch_ms": ksm, "reps": reps, "plan": ctx.blind_rotate_plan(b),
+                         "backend": ctx.backend})
+        ctx.close()
+    print(json.dumps({"metric": "batch_sweep", "unit": "PBS/s and ms per call", "n_gpus": 1, "data": "synthetic",
+                      "note": "cfg2 rows use the aligned decomposer (non-zero digits); inputs resident in HBM; latency = one "
+                              "synchronised tfhe_bootstrap_batch_device call",
+                      "rows": rows}), flush=True)
+
+
 def bench_pool(args, pkg, params, batch, devices, backend):
     """One process, several GPUs: the multi-GPU pool of the C ABI (tfhe_pool_*).  Weak scaling like the
     torch.distributed path: every member bootstraps `batch` ciphertexts per step from a shard resident in ITS device's
@@ -368,6 +506,11 @@ def main():
     ap.add_argument("--no-secondary-legs", action="store_true",
                     help="skip the figures taken after the timed region (aligned decomposer, exact prime-field backend): for "
                          "rocprofv3 --stats runs whose per-kernel averages should contain the timed launches only")
+    ap.add_argument("--batch-sweep", action="store_true",
+                    help="latency of one call and rate of back-to-back calls at batches 1 .. 4096 (the reference's call shape is "
+                         "ONE ciphertext per bootstrap()); prints one JSON line with a row per (workload, batch)")
+    ap.add_argument("--sweep-batches", default="1,8,64,256,1024,4096")
+    ap.add_argument("--sweep-workloads", default="cfg2,cfg3")
     ap.add_argument("--gate", default="", choices=["", "nand", "and", "or", "xor"],
                     help="step = one homomorphic gate over the batch (boolean.rs: bootstrap(2*ct1 + ct0)) instead of a plain PBS")
     args = ap.parse_args()
@@ -446,12 +589,21 @@ def main():
     backend = {"auto": pkg.BACKEND_AUTO, "goldilocks": pkg.BACKEND_GOLDILOCKS, "fp64": pkg.BACKEND_FP64,
                "goldilocks-split": pkg.BACKEND_GOLDILOCKS_SPLIT, "fp64-p49": pkg.BACKEND_FP64_P49,
                "fp64-fft": pkg.BACKEND_FP64_FFT}[args.backend]
+    if args.batch_sweep:
+        return bench_batch_sweep(args, pkg, dev, local_rank, backend)
     if args.kernel == "external_product":
         return bench_external_product(args, pkg, params, batch, dev, rand_words, world, rank, local_rank, backend)
     ctx = pkg.Context(params, device=local_rank, backend=backend)
     backend_name = ctx.backend
     ctx.use_torch_stream()
     ctx.load_bootstrapping_key(bsk, ksk)
+    # the CPU legs re-compute rows of the TIMED batch with the oracle: they need the same keys on the host
+    plain_pbs = not args.gate and not args.scatter_gather
+    check_bits = plain_pbs and not args.no_cpu_baseline
+    host = None
+    if check_bits:
+        u32 = lambda t: t.cpu().numpy().view(np.uint32)
+        host = {"bsk": u32(bsk), "ksk": u32(ksk), "tv": u32(tv)}
     del bsk
     ctx.reserve(batch)
     ctx.set_timing(True)
@@ -501,6 +653,17 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+
+    if check_bits:
+        # rows the CPU legs will re-compute: first, middle, last for the single-thread leg (N = 1), one row per usable host
+        # core for the all-cores leg; at N > 1 every rank checks one row of ITS shard
+        cores = usable_cores()["usable"]
+        single = sorted({0, batch // 2 - 1 if batch > 1 else 0, batch - 1}) if world == 1 else [min(batch - 1, rank * 7919 % batch)]
+        rows = sorted(set(single) | (set(spaced_rows(batch, cores)) if world == 1 else set()))
+        sel = torch.tensor(rows, device=dev, dtype=torch.long)
+        host.update({"rows": rows, "single_rows": single,
+                     "lwe_rows": lwe.index_select(0, sel).cpu().numpy().view(np.uint32),
+                     "gpu_rows": out.index_select(0, sel).cpu().numpy().view(np.uint32)})
 
     total = batch * world * args.steps
     value = total / dt
@@ -589,31 +752,48 @@ def main():
             "ms_per_step": float(t_sg.item()) / sg_steps * 1e3,
             "what": f"rank 0 holds all {batch * world} ciphertexts: isend/recv scatter of {batch * (n + 1) * 4 / 1e6:.0f} MB per peer "
                     "over RCCL/xGMI, local bootstrap, gather back; NOT the headline value"}
-    if not args.gate and not args.scatter_gather and not args.no_secondary_legs and pbs[0] * (32 // pbs[0]) != 32:
+    if plain_pbs and not args.no_secondary_legs and pbs[0] * (32 // pbs[0]) != 32:
         # log2 B does not divide 32 (cfg2: 7): with the reference's literal decomposer the top 32 mod log2 B bits of a
         # word are never decomposed, a trivially encrypted accumulator has no bit below them, every digit is zero and
         # the blind rotation never depends on the key -- in the reference too (decomposer.rs:42-80).  The
         # timed region above therefore multiplies zeros.  The kernels have no data-dependent branch; this leg puts
-        # that on record: the same step with the aligned decomposer, where every CMUX depends on key and data.
+        # that on record: the same step with the aligned decomposer, where every CMUX depends on key and data, with the
+        # headline's warm-up and step counts, its own roofline block, and its rows checked against the oracle below.
         try:
             ctx.set_decomposer_alignment(True)
-            ctx.bootstrap(lwe, tv, out=out)
+            for _ in range(max(1, args.warmup)):
+                ctx.bootstrap(lwe, tv, out=out)
             barrier()
             t_al = time.perf_counter()
-            for _ in range(3):
+            for _ in range(args.steps):
                 ctx.bootstrap(lwe, tv, out=out)
             barrier()
             dt_al = time.perf_counter() - t_al
+            if use_dist:
+                t = torch.tensor([dt_al], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt_al = float(t.item())
+            al_ms = float(np.mean([ctx.kernel_ms_ago(i)[0] for i in range(min(args.steps, 64))]))
             distinct = int(torch.unique(out[:256]).numel())
+            al_achieved = algo_bytes / (al_ms * 1e-3) / 1e9
             result["aligned_decomposer"] = {
-                "kernel_ms": float(np.mean([ctx.kernel_ms_ago(i)[0] for i in range(3)])),
-                "value": batch * 3 / dt_al, "unit": "PBS/s", "steps": 3,
+                "kernel_ms": al_ms,
+                "value": batch * world * args.steps / dt_al, "unit": "PBS/s", "steps": args.steps, "warmup": max(1, args.warmup),
+                "ms_per_step": dt_al / args.steps * 1e3,
+                "roofline": {"kernel": kernel_name, "bound": "valu-issue", "priced_against": "hbm", "achieved": al_achieved,
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": al_achieved / HBM_PEAK_GBS,
+                             "frac_of_measured_hbm": al_achieved / hbm_copy, "kernel_ms": al_ms,
+                             "algorithmic_bytes_per_launch": algo_bytes, "traffic": None},
                 "literal_kernel_ms": br_avg,
                 "distinct_output_words_in_256_rows": distinct,
                 "what": "same step, tfhe_context_set_decomposer_alignment(1): digits are non-zero and the rotation depends on "
                         "the key (the literal cfg2 decomposer yields all-zero digits, in the reference as well); the kernels "
-                        "have no data-dependent branch: what difference there is (a few %) is the clock the chip sustains "
-                        "with non-zero operands in the fp64 datapath, not skipped work"}
+                        "have no data-dependent branch: what difference there is is the clock the chip sustains "
+                        "with non-zero operands in the fp64 datapath, not skipped work.  THIS is the engine's cfg2 rate on "
+                        "data that exercises the datapath"}
+            if check_bits:
+                sel = torch.tensor(host["rows"], device=dev, dtype=torch.long)
+                host["aligned_gpu_rows"] = out.index_select(0, sel).cpu().numpy().view(np.uint32)
             ctx.set_decomposer_alignment(False)
         except Exception as e:  # noqa: BLE001 - a secondary figure must not lose the benchmark line
             result["aligned_decomposer"] = {"error": str(e)}
@@ -647,12 +827,41 @@ def main():
             ctx2.close()
         except Exception as e:  # noqa: BLE001 - a secondary figure must not lose the benchmark line
             result["exact_ntt_backend"] = {"error": str(e)}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_baseline_seconds)
+    # who took part: every rank reports the world size it saw and its device (the first multi-GPU run must show
+    # that N distinct devices really ran)
+    seen = f"rank {rank}/{dist.get_world_size() if use_dist else 1}: cuda:{local_rank} {torch.cuda.get_device_name(local_rank)}"
+    if use_dist:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, seen)
+        seen = gathered
+    else:
+        seen = [seen]
+    result["config"]["ranks_seen"] = seen
+    failed = False
+    if check_bits:
+        if world == 1:
+            result["cpu_baseline"], result["verified"] = cpu_legs(args.workload, args.cpu_baseline_seconds, host)
+            failed = not result["verified"]["bit_exact"]
+        else:
+            # N > 1: no CPU baseline (rank 0 at N = 1 only), but every rank checks one row of ITS shard (schoolbook product)
+            from oracle import oracle as orc
+            orc.build()
+            orc.set_poly_mul_mode(1)
+            p = orc.Params(k, logn, n, orc.Decomposer(*pbs), orc.Decomposer(*ks), log_p=log_p)
+            ok = bool(np.array_equal(orc.bootstrap(p, host["lwe_rows"][0], host["bsk"], host["ksk"], host["tv"]), host["gpu_rows"][0]))
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            result["verified"] = {"rows": world, "bit_exact": bool(flag.item()),
+                                  "what": "one row of every rank's shard of the timed batch re-computed by the oracle on that rank's host"}
+            failed = not result["verified"]["bit_exact"]
+    elif plain_pbs:
+        result["verified"] = None  # --no-cpu-baseline: nothing was re-computed
     if rank == 0:
         print(json.dumps(result), flush=True)
     if use_dist:
         dist.destroy_process_group()
+    if failed:
+        raise SystemExit("bench.py: the GPU's output differs from the oracle's on rows of the timed batch (see `verified`)")
 
 
 if __name__ == "__main__":

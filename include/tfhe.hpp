@@ -500,8 +500,9 @@ BootstrappingKey bootstrapping_key_gen(Engine& e, const LweSecretKey& lwe_secret
     sample_gaussian_slice(p.lwe_std_dev, rng, row + n, 1);
     sample_uniform_slice(rng, row, n);
   }
-  e.check((bmmp ? tfhe_bootstrapping_key_gen_bmmp : tfhe_bootstrapping_key_gen)(
-      e.raw(), lwe_secret_key.data.data(), glwe_secret_key.data.data(), bsk.data(), ksk.data.data(), 1));
+  // (the pool entry point: generated on the first device, installed on EVERY device of the engine)
+  e.check_pool((bmmp ? tfhe_pool_bootstrapping_key_gen_bmmp : tfhe_pool_bootstrapping_key_gen)(
+      e.raw_pool(), lwe_secret_key.data.data(), glwe_secret_key.data.data(), bsk.data(), ksk.data.data(), 1));
   BootstrappingKey bk;
   bk.lwe_sk_ggsw_enc.reserve(ggsws);
   for (size_t i = 0; i < ggsws; ++i)

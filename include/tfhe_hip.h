@@ -379,6 +379,15 @@ int tfhe_pool_load_bootstrapping_key(tfhe_pool *pool, const uint32_t *bsk, const
 int tfhe_pool_load_bootstrapping_key_device(tfhe_pool *pool, const uint32_t *bsk, const uint32_t *ksk);
 /* the BMMP key of tfhe_load_bootstrapping_key_bmmp, replicated the same way */
 int tfhe_pool_load_bootstrapping_key_bmmp(tfhe_pool *pool, const uint32_t *bsk_bmmp, const uint32_t *ksk);
+/* bootstrapping_key_gen (bootstrapping.rs:23-56) on the pool: arguments as tfhe_bootstrapping_key_gen[_bmmp], the key is
+ * generated on member 0's device and, with `load` != 0, installed on EVERY member (prepared once, replicated device to
+ * device like an uploaded key).  tfhe_pool_replicate_key re-replicates whatever key member 0 holds -- after a call that
+ * installed a key on tfhe_pool_member(pool, 0) alone, e.g. tfhe_bootstrapping_key_gen_device with load. */
+int tfhe_pool_bootstrapping_key_gen(tfhe_pool *pool, const uint32_t *lwe_sk, const uint32_t *glwe_sk,
+                                    uint32_t *bsk, uint32_t *ksk, int load);
+int tfhe_pool_bootstrapping_key_gen_bmmp(tfhe_pool *pool, const uint32_t *lwe_sk, const uint32_t *glwe_sk,
+                                         uint32_t *bsk_bmmp, uint32_t *ksk, int load);
+int tfhe_pool_replicate_key(tfhe_pool *pool);
 /* bootstrap() over a host batch sharded across the members; arguments as tfhe_bootstrap_batch. */
 int tfhe_pool_bootstrap_batch(tfhe_pool *pool, const uint32_t *lwe_in, size_t batch,
                               const uint32_t *test_vector_poly, size_t tv_count, uint32_t *lwe_out);
@@ -387,7 +396,12 @@ int tfhe_pool_gate_batch(tfhe_pool *pool, const uint32_t truth[4], const uint32_
                          const uint32_t *ct1, size_t batch, uint32_t *lwe_out);
 /* Device-resident shards: member i bootstraps counts[i] ciphertexts at lwe_in[i] (a pointer on ITS device) with
  * test vector(s) tv[i] (tv_counts[i] = 1 or counts[i]) into lwe_out[i].  Enqueues on every member's stream and
- * returns; tfhe_pool_synchronize waits.  counts[i] = 0 skips a member. */
+ * returns; tfhe_pool_synchronize waits.  counts[i] = 0 skips a member.  Arguments of all members are checked before
+ * anything is enqueued (a failing call has launched nothing).
+ * ORDERING CONTRACT: member i's work runs on member i's stream -- its own non-blocking stream unless
+ * tfhe_context_set_stream(tfhe_pool_member(pool, i), s) gave it one.  The call does NOT order against whatever stream
+ * produced lwe_in[i] / tv[i] or will consume lwe_out[i]: the caller synchronises those producers first (or hands every
+ * member the producing stream), and must keep the buffers alive until tfhe_pool_synchronize. */
 int tfhe_pool_bootstrap_shards_device(tfhe_pool *pool, const uint32_t *const *lwe_in, const size_t *counts,
                                       const uint32_t *const *test_vector_poly, const size_t *tv_counts,
                                       uint32_t *const *lwe_out);
@@ -422,6 +436,13 @@ int tfhe_debug_fft_margin(tfhe_context *ctx, double *worst, int reset);
  * returns -- the caller still orders everything on the one stream it gave (tfhe_context_set_stream). */
 int tfhe_debug_blind_rotate_plan(tfhe_context *ctx, size_t batch, size_t *samples_per_group, unsigned *segments,
                                  unsigned *streams, size_t *resident_samples);
+
+/* The kernel shape behind that plan: waves of one workgroup that work on a sample's rotation -- (k+1) x waves per
+ * polynomial for the throughput kernel (shared by *samples_per_team samples where two fit), 2 (k+1) for the wide team
+ * that batches too small to fill the chip get (one sample per workgroup; the latency shape of the reference's
+ * one-ciphertext bootstrap(), bootstrapping.rs:58-65). */
+int tfhe_debug_blind_rotate_shape(tfhe_context *ctx, size_t batch, unsigned *waves_per_sample,
+                                  unsigned *samples_per_team);
 
 /* Library / build identification */
 const char *tfhe_version(void);

@@ -4,7 +4,11 @@
  *   - tfhe_bootstrap_batch through one context, tfhe_pool_bootstrap_batch through a pool of two members on device 0:
  *     same words (bootstraps are pure functions of ciphertext, test vector and keys: bootstrapping.rs:58-120);
  *   - a NAND gate stream through the pool against the single context (boolean.rs:9-53 through the closure hook);
- *   - error behaviour: statuses, never a crash (the reference panics). */
+ *   - error behaviour: statuses, never a crash (the reference panics);
+ *   - the committed golden fixtures (argv[1..]: directories under tests/golden/, each one bsk / ksk / lwe_in / tv / lwe_out
+ *     in the library's on-disk format): read with tfhe_file_read, bootstrapped through tfhe_bootstrap_batch and
+ *     tfhe_pool_bootstrap_batch, every output word memcmp'ed with lwe_out -- results, not only linkage, with no Python
+ *     on the caller's side. */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -28,7 +32,70 @@ static uint32_t next_u32(void) { /* SplitMix64 */
     }                                                                                \
   } while (0)
 
-int main(void) {
+/* one array of a fixture set: header (kind, params, dims) + words; NULL on any failure */
+static uint32_t *read_fixture(const char *dir, const char *name, tfhe_params *params, uint32_t dims[4], uint32_t *ndims,
+                              uint32_t *flags) {
+  char path[1024];
+  uint32_t kind = 0;
+  uint64_t words = 0;
+  snprintf(path, sizeof path, "%s/%s.tfhe", dir, name);
+  if (tfhe_file_read_header(path, &kind, params, flags, dims, ndims, &words) != TFHE_OK) {
+    fprintf(stderr, "cannot read the header of %s\n", path);
+    return NULL;
+  }
+  uint32_t *data = malloc(words ? words * 4 : 4);
+  if (!data || tfhe_file_read(path, data, words) != TFHE_OK) {
+    fprintf(stderr, "cannot read %s\n", path);
+    free(data);
+    return NULL;
+  }
+  return data;
+}
+
+/* bootstrap the fixture's inputs through a single context and through a two-member pool; compare with its lwe_out */
+static int golden_set(const char *dir) {
+  tfhe_params p, q;
+  uint32_t dims[4], nd = 0, flags = 0, lwe_dims[4], aligned = 0;
+  uint32_t *bsk = read_fixture(dir, "bsk", &p, dims, &nd, &aligned);
+  uint32_t *ksk = read_fixture(dir, "ksk", &q, dims, &nd, &flags);
+  uint32_t *lwe = read_fixture(dir, "lwe_in", &q, lwe_dims, &nd, &flags);
+  uint32_t *tv = read_fixture(dir, "tv", &q, dims, &nd, &flags);
+  uint32_t *want = read_fixture(dir, "lwe_out", &q, dims, &nd, &flags);
+  if (!bsk || !ksk || !lwe || !tv || !want) return 20;
+  const size_t batch = lwe_dims[0], n = p.lwe_dimension;
+  if (lwe_dims[1] != n + 1 || batch == 0) return 21;
+  uint32_t *got = malloc(batch * (n + 1) * 4);
+  if (!got) return 2;
+  tfhe_context *ctx = NULL;
+  CHECK(tfhe_context_create(&p, 0, &ctx), TFHE_OK);
+  CHECK(tfhe_context_set_decomposer_alignment(ctx, (aligned & TFHE_FILE_FLAG_ALIGNED) ? 1 : 0), TFHE_OK);
+  CHECK(tfhe_load_bootstrapping_key(ctx, bsk, ksk), TFHE_OK);
+  memset(got, 0xA5, batch * (n + 1) * 4);
+  CHECK(tfhe_bootstrap_batch(ctx, lwe, batch, tv, 1, got), TFHE_OK);
+  if (memcmp(got, want, batch * (n + 1) * 4) != 0) {
+    fprintf(stderr, "%s: tfhe_bootstrap_batch differs from the fixture's lwe_out\n", dir);
+    return 22;
+  }
+  const int devices[2] = {0, 0};
+  tfhe_pool *pool = NULL;
+  CHECK(tfhe_pool_create(&p, devices, 2, TFHE_BACKEND_AUTO, &pool), TFHE_OK);
+  CHECK(tfhe_pool_set_decomposer_alignment(pool, (aligned & TFHE_FILE_FLAG_ALIGNED) ? 1 : 0), TFHE_OK);
+  CHECK(tfhe_pool_load_bootstrapping_key(pool, bsk, ksk), TFHE_OK);
+  memset(got, 0x5A, batch * (n + 1) * 4);
+  CHECK(tfhe_pool_bootstrap_batch(pool, lwe, batch, tv, 1, got), TFHE_OK);
+  if (memcmp(got, want, batch * (n + 1) * 4) != 0) {
+    fprintf(stderr, "%s: tfhe_pool_bootstrap_batch differs from the fixture's lwe_out\n", dir);
+    return 23;
+  }
+  printf("golden OK: %s (%zu ciphertexts, backend %s; single context and pool of 2 == lwe_out)\n", dir, batch,
+         tfhe_context_backend(ctx));
+  tfhe_pool_destroy(pool);
+  tfhe_context_destroy(ctx);
+  free(bsk); free(ksk); free(lwe); free(tv); free(want); free(got);
+  return 0;
+}
+
+int main(int argc, char **argv) {
   tfhe_params p;
   tfhe_params_default(&p, 1); /* N = 512, k = 2, n = 4, PBS l = 6 logB = 4, KS l = 5 logB = 4 */
   CHECK(tfhe_params_validate(&p), TFHE_OK);
@@ -86,5 +153,9 @@ int main(void) {
   tfhe_pool_destroy(pool);
   tfhe_context_destroy(ctx);
   free(bsk); free(ksk); free(lwe); free(lwe2); free(tv); free(one); free(two);
+  for (int i = 1; i < argc; ++i) {
+    int rc = golden_set(argv[i]);
+    if (rc) return rc;
+  }
   return 0;
 }

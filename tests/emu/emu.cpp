@@ -254,6 +254,100 @@ void glwe_body(u32 k, size_t rows, const u32* glwe, const u32* sk, u32* out, int
   }
 }
 
+// ---- the wide team (pbs_wave.h::blind_rotate_team_wide): 2 (K+1) waves per sample, one row buffer per digit row ----
+template <class Elem>
+struct HostWideTeam {
+  int n, ns, rows, waves;
+  std::vector<Elem> buffers, tw, tw_natural;  // buffers: rows x ns
+  std::vector<u32> acc;                       // (K+1) x n
+  pthread_barrier_t team_bar;
+  std::vector<pthread_barrier_t> wave_bars;
+};
+template <class Elem>
+struct HostWideWave {
+  int lane_, wave_;
+  HostWideTeam<Elem>* t_;
+  int row_;
+  int tid() const { return lane_; }
+  int group() const { return wave_ >> 1; }
+  int half() const { return wave_ & 1; }
+  int wave_index() const { return wave_; }
+  HostWideWave with_row(int r) const {
+    HostWideWave w = *this;
+    w.row_ = r;
+    return w;
+  }
+  const Elem* row_buffer(int r) const { return t_->buffers.data() + (size_t)r * t_->ns; }
+  void wave_sync() const { pthread_barrier_wait(&t_->wave_bars[wave_]); }
+  void poly_sync() const { wave_sync(); }
+  void team_sync() const { pthread_barrier_wait(&t_->team_bar); }
+  Elem* scratch() const { return t_->buffers.data() + (size_t)row_ * t_->ns; }
+  u32* acc(int = 0) const { return t_->acc.data() + (size_t)group() * t_->n; }
+  const Elem* twiddles() const { return t_->tw.data(); }
+  const Elem* twiddles_uniform() const { return t_->tw_natural.data(); }
+  u32 uniform(u32 v) const { return v; }
+  // two waves add to one word here (the halves of a column): the emulator's lanes are OS threads, so this one is atomic
+  void lds_add(u32* p, u32 v) const { __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+  void compiler_fence() const {}
+};
+
+template <class F, int LOGN, int K>
+void blind_rotate_wide(const PbsParams& P, size_t batch, const u32* lwe, const u32* tv, size_t tv_stride,
+                       const typename F::elem* bsk, u32* out_glwe, u32* out_lwe) {
+  typedef typename F::elem elem;
+  constexpr int N = 1 << LOGN;
+  constexpr int LT = LOGN - F::kLogShrink;
+  HostWideTeam<elem> team;
+  team.n = N;
+  team.ns = 1 << LT;
+  team.waves = 2 * (K + 1);
+  team.rows = (K + 1) * (P.levels > 2 ? (int)P.levels : 2);
+  team.buffers.resize((size_t)team.rows * team.ns);
+  team.acc.resize((size_t)(K + 1) * N);
+  team.tw_natural.resize(ntt_twiddle_words(team.ns));
+  F::fill_twiddles(LT, team.tw_natural.data());
+  team.tw.resize(team.tw_natural.size());
+  for (int tid = 0; tid < 64; ++tid) ntt_stage_twiddles<LT, 1>(team.tw.data(), team.tw_natural.data(), tid, 64);
+  pthread_barrier_init(&team.team_bar, nullptr, team.waves * kWave);
+  team.wave_bars.resize(team.waves);
+  for (auto& b : team.wave_bars) pthread_barrier_init(&b, nullptr, kWave);
+  std::vector<u32> state((size_t)(K + 1) * N);
+  auto body = [&](const HostWideWave<elem>& w) {
+    constexpr int EC = N / 64;
+    const int me = w.group(), q = w.half(), lane = w.tid();
+    for (size_t b = 0; b < batch; ++b) {
+      const u32 per = (P.n + g_segments - 1) / g_segments;
+      for (u32 i0 = 0; i0 < P.n; i0 += per) {
+        const u32 i1 = i0 + per < P.n ? i0 + per : P.n;
+        blind_rotate_team_wide<F, LOGN, K>(w, P, lwe + b * (P.n + 1), tv + b * tv_stride, bsk, i0, i1, state.data());
+        if (i1 < P.n) {  // park, as blind_rotate_wide_kernel does: each half the words it owns
+          for (int r = 0; r < EC / 2; ++r) {
+            const int j = (r + q * (EC / 2)) * 64 + lane;
+            state[(size_t)me * N + j] = w.acc()[j];
+          }
+          w.team_sync();
+        }
+      }
+      const u32* acc = w.acc();
+      for (int r = 0; r < EC / 2; ++r) {
+        const int x = (r + q * (EC / 2)) * 64 + lane;
+        if (out_glwe) out_glwe[(b * (K + 1) + me) * N + x] = acc[x];
+        if (out_lwe && me < K) out_lwe[b * ((size_t)K * N + 1) + me * N + x] = (x == 0) ? acc[0] : (0u - acc[N - x]);
+      }
+      if (out_lwe && me == K && q == 0 && lane == 0) out_lwe[b * ((size_t)K * N + 1) + K * N] = acc[0];
+      w.team_sync();
+    }
+  };
+  std::vector<std::thread> th;
+  for (int wv = 0; wv < team.waves; ++wv)
+    for (int l = 0; l < kWave; ++l)
+      th.emplace_back([&, wv, l] {
+        HostWideWave<elem> ctx{l, wv, &team, wv};
+        body(ctx);
+      });
+  for (auto& t : th) t.join();
+}
+
 bool g_aligned = false;  // decomposer alignment extension (tfhe_hip.h)
 
 PbsParams make_params(u32 n, u32 k, u32 log_n, u32 log_p, u32 padding, u32 log_base, u32 levels) {
@@ -379,6 +473,20 @@ int emu_blind_rotate(int field, int g, u32 n, u32 k, u32 logn, u32 log_p, u32 pa
   if (k == 1) { DISPATCH_FIELD(field, DISPATCH_LOGN(logn, g, (blind_rotate<FF, L, 1, GG>(P, batch, lwe, tv, tv_stride, (const FF::elem*)bsk, out_glwe, out_lwe)))); }
   else if (k == 2) { DISPATCH_FIELD(field, DISPATCH_LOGN(logn, g, (blind_rotate<FF, L, 2, GG>(P, batch, lwe, tv, tv_stride, (const FF::elem*)bsk, out_glwe, out_lwe)))); }
   else return 2;
+  return 0;
+}
+
+// the wide team: the complex transform, N = 512 / 1024, k = 1 / 2
+int emu_blind_rotate_wide(u32 n, u32 k, u32 logn, u32 log_p, u32 padding, u32 log_base, u32 levels, size_t batch,
+                          const u32* lwe, const u32* tv, size_t tv_stride, const void* bsk, u32* out_glwe, u32* out_lwe) {
+  PbsParams P = make_params(n, k, logn, log_p, padding, log_base, levels);
+  typedef FftField FF;
+  const FF::elem* key = (const FF::elem*)bsk;
+  if (logn == 9 && k == 1) blind_rotate_wide<FF, 9, 1>(P, batch, lwe, tv, tv_stride, key, out_glwe, out_lwe);
+  else if (logn == 9 && k == 2) blind_rotate_wide<FF, 9, 2>(P, batch, lwe, tv, tv_stride, key, out_glwe, out_lwe);
+  else if (logn == 10 && k == 1) blind_rotate_wide<FF, 10, 1>(P, batch, lwe, tv, tv_stride, key, out_glwe, out_lwe);
+  else if (logn == 10 && k == 2) blind_rotate_wide<FF, 10, 2>(P, batch, lwe, tv, tv_stride, key, out_glwe, out_lwe);
+  else return 1;
   return 0;
 }
 

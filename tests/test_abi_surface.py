@@ -91,3 +91,39 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "tfhe_oracle" not in text and "from oracle" not in text and "import oracle" not in text, f
+
+
+def _version() -> str:
+    lib = pkg().lib()
+    lib.tfhe_version.restype = C.c_char_p
+    return lib.tfhe_version().decode()
+
+
+def test_shipped_library_is_not_a_dev_build():
+    """tfhe_version() of the shipped library carries no build tag: a dev build (the only kind that may compile a WRONG-BITS
+    timing probe in, csrc/dev_switches.h), the rounding-margin probe build and subset builds all say so in brackets"""
+    v = _version()
+    assert v.startswith("tfhe-research_amd ") and "[" not in v and "DEV" not in v and "WRONG" not in v, v
+
+
+def test_wrong_bits_probes_need_a_dev_build():
+    """csrc/dev_switches.h: a TFHE_PROBE_* switch without TFHE_DEV_BUILD does not compile; with it, it does; and the shipped
+    recipe (tfhe-research_amd/build.py) refuses to pass either"""
+    import subprocess
+    from importlib import import_module
+    csrc = os.path.join(ROOT, "tfhe-research_amd", "csrc")
+    base = ["g++", "-std=c++17", "-fsyntax-only", "-x", "c++", "-I", csrc, os.path.join(csrc, "platform.h")]
+    for probe in ("TFHE_PROBE_HOT_KEY", "TFHE_PROBE_NO_EXCHANGE_READS", "TFHE_PROBE_NO_TRANSPOSE", "TFHE_PROBE_NO_TEAM_SYNC"):
+        bad = subprocess.run(base + [f"-D{probe}=1"], capture_output=True, text=True)
+        assert bad.returncode != 0 and "TFHE_DEV_BUILD" in bad.stderr, probe
+        ok = subprocess.run(base + [f"-D{probe}=1", "-DTFHE_DEV_BUILD"], capture_output=True, text=True)
+        assert ok.returncode == 0, ok.stderr
+    # no other header defines a probe default any more (one place: dev_switches.h)
+    for f in os.listdir(csrc):
+        if f != "dev_switches.h" and f.endswith((".h", ".hip", ".cpp")):
+            assert "#define TFHE_PROBE_" not in open(os.path.join(csrc, f)).read(), f
+    pkg()
+    builder = import_module("tfhe_research_amd.build")
+    for flag in ("-DTFHE_DEV_BUILD", "-DTFHE_PROBE_HOT_KEY=1"):
+        with pytest.raises(ValueError):
+            builder._compile("/tmp/never.so", [flag], False, "never")

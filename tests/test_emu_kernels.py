@@ -432,6 +432,69 @@ def test_two_samples_per_team_vs_oracle(emu, oracle, k, logn, n, pbs, log_p, g):
         assert np.array_equal(ext[b], tr["extracted_lwe"]), f"sample {b}"
 
 
+WIDE_CASES = [
+    (1, 10, 4, (7, 3), 2),    # cfg2's shape: levels 2 + 1 over the two halves (the literal, misaligned decomposer)
+    (1, 10, 3, (8, 4), 2),    # every CMUX depends on the key; levels 2 + 2
+    (2, 9, 4, (4, 6), 2),     # the reference's parameters: six waves, 18 digit rows, odd chunk count per level
+    (1, 9, 5, (8, 2), 2),     # cfg1's shape: one level per half
+    (2, 10, 3, (10, 3), 2),   # an admission-edge shape of the rounding bound
+    (1, 10, 3, (9, 1), 2),    # ONE level: the second half transforms nothing, more waves than digit rows
+    (1, 9, 3, (5, 5), 4),     # five levels (3 + 2), log_p = 4
+]
+
+
+@pytest.mark.parametrize("k,logn,n,pbs,log_p", WIDE_CASES)
+@pytest.mark.parametrize("segments", [1, 2])
+def test_wide_team_blind_rotation_vs_oracle(emu, oracle, k, logn, n, pbs, log_p, segments):
+    """pbs_wave.h::blind_rotate_team_wide -- the latency shape for small batches: 2 (k+1) waves per sample, wave (c, q)
+    transforms half of polynomial c's digit levels, accumulates key part q of column c over all rows, inverse-transforms
+    that one accumulator and adds lift << 16 q into the accumulator polynomial.  Same words as the reference's loop
+    (oracle trace): a~ = 0 and b~ -> 2N rows, per-sample test vectors, whole and segmented rotations."""
+    if not field_exact(FFT, k, logn, pbs):
+        pytest.skip("outside the rounding bound")
+    params = oracle.Params(k, logn, n, oracle.Decomposer(*pbs), log_p=log_p)
+    batch = 3
+    lwe, bsk, ksk, _ = oracle.synthetic_inputs(params, batch, cfg_index=130 + logn + k)
+    rng = np.random.default_rng(logn * 5 + k)
+    tvs = rng.integers(0, 1 << log_p, size=(batch, params.N)).astype(np.uint32)
+    lwe = lwe.copy()
+    lwe[0, 0] = 0
+    lwe[1, n] = 0xFFFFFFFF
+    spec = prepared(emu, FFT, params, bsk, 1)
+    glwe = np.zeros((batch, k + 1, params.N), dtype=np.uint32)
+    ext = np.zeros((batch, params.big_n + 1), dtype=np.uint32)
+    emu.emu_set_segments(segments)
+    try:
+        rc = emu.emu_blind_rotate_wide(n, k, logn, log_p, 1, pbs[0], pbs[1], C.c_size_t(batch), p32(lwe), p32(tvs),
+                                       C.c_size_t(params.N), p64(spec), p32(glwe), p32(ext))
+    finally:
+        emu.emu_set_segments(1)
+    assert rc == 0
+    for b in range(batch):
+        _, tr = oracle.bootstrap(params, lwe[b], bsk, ksk, tvs[b], trace=True)
+        assert np.array_equal(glwe[b], tr["acc_final"]), f"sample {b}"
+        assert np.array_equal(ext[b], tr["extracted_lwe"]), f"sample {b}"
+
+
+def test_wide_team_with_the_aligned_decomposer(emu, oracle):
+    """cfg2's base (log2 B = 7) with the aligned decomposer: the data-dependent case of the headline parameters"""
+    params = oracle.Params(1, 10, 4, oracle.Decomposer(7, 3), log_p=2)
+    lwe, bsk, ksk, tv = oracle.synthetic_inputs(params, 2, cfg_index=141)
+    spec = prepared(emu, FFT, params, bsk, 1)
+    glwe = np.zeros((2, 2, params.N), dtype=np.uint32)
+    emu.emu_set_aligned(1)
+    try:
+        with oracle.decomposer_aligned(True):
+            rc = emu.emu_blind_rotate_wide(4, 1, 10, 2, 1, 7, 3, C.c_size_t(2), p32(lwe), p32(tv), C.c_size_t(0), p64(spec),
+                                           p32(glwe), None)
+            assert rc == 0
+            for b in range(2):
+                _, tr = oracle.bootstrap(params, lwe[b], bsk, ksk, tv, trace=True)
+                assert np.array_equal(glwe[b], tr["acc_final"]), f"sample {b}"
+    finally:
+        emu.emu_set_aligned(0)
+
+
 @pytest.mark.parametrize("field,k,logn,n,pbs,log_p,g,ns,segments", [(FFT, 2, 9, 5, (4, 6), 2, 1, 2, 2), (FFT, 1, 10, 5, (8, 4), 2, 1, 1, 3),
                                                                      (FFT, 2, 11, 3, (8, 4), 4, 4, 2, 3), (FP, 1, 9, 4, (8, 2), 2, 1, 1, 4)])
 def test_segmented_blind_rotation_vs_oracle(emu, oracle, field, k, logn, n, pbs, log_p, g, ns, segments):

@@ -6,6 +6,8 @@ listed several times, so pools [0], [0, 0] and [0, 0, 0] exercise everything but
 creation, the prepared-key replication (a device-to-device copy instead of a peer copy), the slice rule, one host thread
 per member, per-member streams, the device-shard entry point.  Outputs must equal the single-context run, the committed
 golden fixtures and the oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -136,3 +138,143 @@ def test_pool_error_behaviour(oracle):
         with pytest.raises(m.TfheError) as e:
             pool.bootstrap(lwe, tv)                  # no key yet
         assert e.value.status == m.TFHE_ERR_NO_KEY and "member 0" in str(e.value)
+
+
+def test_pool_keygen_installs_the_new_key_on_every_member(oracle):
+    """a key GENERATED through the pool replaces a key LOADED before it on every member -- not on member 0
+    alone (the other members would then bootstrap their slices under the old key, silently).  Pool [0, 0]: load key A,
+    generate key B (tfhe_pool_bootstrapping_key_gen, load = 1), bootstrap: every slice equals a single context under B,
+    and differs from the run under A; replicate_key() after a member-0-only install repairs the same situation."""
+    m = pkg()
+    p = oracle.Params(1, 10, 8, oracle.Decomposer(8, 4))   # log2 B divides 32: the rotation depends on the key
+    pp = to_pkg_params(p)
+    lwe, bsk_a, ksk_a, tv = oracle.synthetic_inputs(p, 10, cfg_index=51)
+    rng = np.random.default_rng(5)
+    with m.Pool(pp, [0, 0]) as pool:
+        pool.load_bootstrapping_key(bsk_a, ksk_a)
+        under_a = pool.bootstrap(lwe, tv)
+        lwe_sk, glwe_sk, bsk_b, ksk_b = pool.generate_keys(rng=rng, load=True)
+        under_b = pool.bootstrap(lwe, tv)
+        # member-0-only install of A again, then the public re-replication
+        pool.member(0).load_bootstrapping_key(bsk_a, ksk_a)
+        pool.replicate_key()
+        again_a = pool.bootstrap(lwe, tv)
+    with m.Context(pp) as ctx:
+        ctx.load_bootstrapping_key(bsk_b, ksk_b)
+        want_b = ctx.bootstrap(lwe, tv)
+    assert np.array_equal(under_b, want_b)            # BOTH slices (rows 0-4 and 5-9) under the generated key
+    assert not np.array_equal(under_b[5:], under_a[5:])
+    assert np.array_equal(again_a, under_a)
+    for b in (0, 4, 5, 9):
+        assert np.array_equal(under_b[b], oracle.bootstrap(p, lwe[b], bsk_b, ksk_b, tv)), b
+
+
+def test_pool_shards_are_all_or_nothing_on_bad_arguments(oracle):
+    """tfhe_pool_bootstrap_shards_device validates every member before it enqueues anything"""
+    import torch
+    m = pkg()
+    p = oracle.Params(1, 10, 4, oracle.Decomposer(7, 3))
+    lwe, bsk, ksk, tv = oracle.synthetic_inputs(p, 8, cfg_index=61)
+    dev = torch.device("cuda", 0)
+    to_d = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to(dev)
+    with m.Pool(to_pkg_params(p), [0, 0]) as pool:
+        pool.load_bootstrapping_key(bsk, ksk)
+        pool.reserve(8)
+        outs = [torch.full((4, p.n + 1), 7, dtype=torch.int32, device=dev) for _ in range(2)]
+        bad_tv = to_d(np.zeros((3, p.N), dtype=np.uint32))   # 3 test vectors for 4 rows: invalid for member 1
+        with pytest.raises(m.TfheError) as e:
+            pool.bootstrap_shards([to_d(lwe[:4]), to_d(lwe[4:])], [to_d(tv), bad_tv], outs)
+        assert e.value.status == m.TFHE_ERR_INVALID_ARGUMENT and "member 1" in str(e.value)
+        pool.synchronize()
+        assert int((outs[0] != 7).sum()) == 0     # member 0 launched nothing either
+
+
+# ---- more than one GPU: skipped on the one-GPU development box, run wherever a node is visible --------------------------
+def _device_count() -> int:
+    import torch
+    return torch.cuda.device_count()
+
+
+def _multi_device_lists():
+    n = _device_count()
+    lists = [[0, 1]] if n >= 2 else []
+    if n > 2:
+        lists.append(list(range(n)))
+    return lists
+
+
+@pytest.mark.parametrize("name", ["ref_test", "n1024_full_word"])
+def test_pool_over_distinct_devices_reproduces_the_golden_outputs(name, oracle):
+    """The peer-copy branch of the key replication (capi.cpp adopt_prepared_key: hipDeviceCanAccessPeer /
+    hipDeviceEnablePeerAccess / hipMemcpyPeerAsync) and members on DIFFERENT devices: pools [0, 1] and all visible
+    devices ≡ the golden files ≡ a single context on device 0 ≡ a single context on the last device."""
+    lists = _multi_device_lists()
+    if not lists:
+        pytest.skip(f"needs >= 2 GPUs (hipGetDeviceCount = {_device_count()})")
+    m = pkg()
+    pd, a = gc.load_set(name)
+    for devices in lists:
+        with m.Pool(pkg_params(pd), devices) as pool:
+            pool.load_bootstrapping_key(a["bsk"], a["ksk"])
+            assert np.array_equal(pool.bootstrap(a["lwe_in"], a["tv"]), a["lwe_out"]), devices
+    with m.Context(pkg_params(pd), device=lists[-1][-1]) as ctx:   # a context that is not on device 0
+        ctx.load_bootstrapping_key(a["bsk"], a["ksk"])
+        assert np.array_equal(ctx.bootstrap(a["lwe_in"], a["tv"]), a["lwe_out"])
+
+
+def test_pool_over_distinct_devices_full_size(oracle):
+    """cfg2 parameters, a ragged 1,001-row batch with the aligned decomposer (key-dependent) over every visible device,
+    device-resident shards included: every word equals the single-context run, edge rows of every slice the oracle's"""
+    lists = _multi_device_lists()
+    if not lists:
+        pytest.skip(f"needs >= 2 GPUs (hipGetDeviceCount = {_device_count()})")
+    import torch
+    m = pkg()
+    p = oracle.CFG2
+    _, bsk, ksk, tv = oracle.synthetic_inputs(p, 1, cfg_index=2)
+    rng = np.random.default_rng(78)
+    batch = 1001
+    lwe = rand_u32(rng, (batch, p.n + 1))
+    with m.Context(to_pkg_params(p)) as ctx:
+        ctx.set_decomposer_alignment(True)
+        ctx.load_bootstrapping_key(bsk, ksk)
+        want = ctx.bootstrap(lwe, tv)
+    devices = lists[-1]
+    with m.Pool(to_pkg_params(p), devices) as pool:
+        pool.set_decomposer_alignment(True)
+        pool.load_bootstrapping_key(bsk, ksk)
+        got = pool.bootstrap(lwe, tv)
+        assert np.array_equal(got, want)
+        # the enqueue-only entry point with shards resident on the members' own devices
+        pool.reserve(batch)
+        shards, tvs, outs = [], [], []
+        for i, d in enumerate(devices):
+            first, count = pool.shard(batch, i)
+            dev = torch.device("cuda", d)
+            shards.append(torch.from_numpy(lwe[first:first + count].view(np.int32)).to(dev))
+            tvs.append(torch.from_numpy(tv.view(np.int32)).to(dev))
+            outs.append(torch.empty_like(shards[-1]))
+        pool.bootstrap_shards(shards, tvs, outs)
+        pool.synchronize()
+        assert np.array_equal(np.concatenate([o.cpu().numpy().view(np.uint32) for o in outs]), want)
+        edges = sorted({pool.shard(batch, i)[0] for i in range(len(devices))} | {batch - 1})
+    with oracle.decomposer_aligned(True):
+        for b in edges[:6]:
+            assert np.array_equal(got[b], oracle.bootstrap(p, lwe[b], bsk, ksk, tv)), b
+
+
+def test_sharded_bootstrap_over_rccl_two_ranks(tmp_path):
+    """One process per GPU: `torch.distributed.run` with 2 ranks and backend nccl (= RCCL) runs
+    sharding.replicate_keys + sharding.bootstrap_sharded (scatter over RCCL, local bootstrap, gather) and rank 0
+    compares the gathered rows with a single-context run and the golden fixture."""
+    if _device_count() < 2:
+        pytest.skip(f"needs >= 2 GPUs (hipGetDeviceCount = {_device_count()})")
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_two_rank_probe.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533", script],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "rccl two-rank OK" in out.stdout

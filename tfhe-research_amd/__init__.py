@@ -422,8 +422,15 @@ class Context:
         self._check(lib().tfhe_debug_blind_rotate_plan(self._h, C.c_size_t(batch), C.byref(group), C.byref(segments),
                                                        C.byref(streams), C.byref(resident)))
         groups = -(-batch // max(1, group.value))
+        waves, per_team = C.c_uint(), C.c_uint()
+        self._check(lib().tfhe_debug_blind_rotate_shape(self._h, C.c_size_t(batch), C.byref(waves), C.byref(per_team)))
+        k1 = self.params.k + 1
         return {"samples_per_group": group.value, "groups": groups, "segments": segments.value, "streams": streams.value,
-                "launches": groups * segments.value * streams.value, "resident_samples": resident.value}
+                "launches": groups * segments.value * streams.value, "resident_samples": resident.value,
+                "waves_per_team": waves.value, "samples_per_team": per_team.value,
+                "kernel": "wide team (2 waves per polynomial: split by level and key part)"
+                          if waves.value == 2 * k1 and per_team.value == 1 and segments.value == 1 and self.backend == "fp64-fft"
+                          and self.params.glwe_poly_degree <= 10 else "team"}
 
     def last_kernel_ms(self):
         br, ks = C.c_float(), C.c_float()
@@ -979,6 +986,30 @@ class Pool:
         assert bsk.shape == p.bsk_shape() and ksk.shape == p.ksk_shape()
         self._check(lib().tfhe_pool_load_bootstrapping_key(self._h, _hp(bsk), _hp(ksk)))
 
+    def replicate_key(self):
+        """copy whatever key member 0 holds (prepared form + KSK) to every other member, device to device"""
+        self._check(lib().tfhe_pool_replicate_key(self._h))
+
+    def bootstrapping_key_gen(self, lwe_sk, glwe_sk, bsk_samples, ksk_samples, load: bool = True, bmmp: bool = False):
+        """bootstrapping_key_gen (bootstrapping.rs:23-56) on pre-filled host buffers -> (bsk, ksk); generated on member
+        0's device and, with `load`, installed on EVERY member (tfhe_pool_bootstrapping_key_gen[_bmmp])."""
+        p = self.params
+        lsk, gsk = _np(lwe_sk).reshape(p.n), _np(glwe_sk).reshape(p.k, p.N)
+        bsk, ksk = _np(bsk_samples).copy(), _np(ksk_samples).copy()
+        assert bsk.shape == (p.bsk_bmmp_shape() if bmmp else p.bsk_shape()) and ksk.shape == p.ksk_shape()
+        fn = lib().tfhe_pool_bootstrapping_key_gen_bmmp if bmmp else lib().tfhe_pool_bootstrapping_key_gen
+        self._check(fn(self._h, _hp(lsk), _hp(gsk), _hp(bsk), _hp(ksk), C.c_int(int(load))))
+        return bsk, ksk
+
+    def generate_keys(self, rng=None, load: bool = True, bmmp: bool = False):
+        """Context.generate_keys for the pool: secrets and samples drawn on the host (OS CSPRNG unless the test hook
+        `rng=` is given), key material completed on member 0's GPU and, with `load`, installed on every member.
+        -> (lwe_sk, glwe_sk, bsk, ksk)"""
+        lwe_sk, glwe_sk, bsk, ksk = self.member(0).generate_keys(rng=rng, load=load, bmmp=bmmp)
+        if load:
+            self.replicate_key()
+        return lwe_sk, glwe_sk, bsk, ksk
+
     def bootstrap(self, lwe_in, test_vector_poly) -> np.ndarray:
         """bootstrap() over a host batch [batch][n+1], sharded over the members"""
         lwe, tv = _np(lwe_in).reshape(-1, self.io_dim + 1), _np(test_vector_poly)
@@ -998,8 +1029,15 @@ class Pool:
 
     def bootstrap_shards(self, lwe_shards, tv_shards, out_shards):
         """Device-resident shards (torch tensors, shard i on member i's device; None or an empty shard skips the
-        member): enqueues on every member's stream and returns -- synchronize() waits."""
+        member): enqueues on every member's stream and returns -- synchronize() waits.
+        Ordering (tfhe_hip.h, tfhe_pool_bootstrap_shards_device): a member's work runs on ITS stream, not on the torch
+        stream that filled the shard, so this first waits for the torch current stream of every shard's device (a no-op
+        when it is idle); the OUTPUTS are ready -- and the shard tensors may be freed or refilled -- only after
+        synchronize()."""
         n = len(self)
+        import torch
+        for dev in {t.device for t in list(lwe_shards) + list(tv_shards) if t is not None and t.is_cuda}:
+            torch.cuda.current_stream(dev).synchronize()
         assert len(lwe_shards) == n and len(tv_shards) == n and len(out_shards) == n
         ptrs_in, ptrs_tv, ptrs_out = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_void_p * n)()
         counts, tv_counts = (C.c_size_t * n)(), (C.c_size_t * n)()

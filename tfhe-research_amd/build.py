@@ -43,6 +43,10 @@ def is_stale(lib: str = LIB) -> bool:
 def _compile(lib: str, extra, verbose: bool, tag: str, force: bool = False) -> str:
     """One object per source under _build/<tag>/ (kernels.hip is 2.5 minutes of device code, the host sources are
     seconds: an edit of capi.cpp or pool.cpp does not rebuild the kernels), then one link."""
+    # the shipped recipe never builds a library that may compute wrong bits (csrc/dev_switches.h)
+    for flag in extra:
+        if "TFHE_DEV_BUILD" in flag or "TFHE_PROBE_" in flag:
+            raise ValueError(f"build.py does not build dev/probe libraries: {flag} (use tools/dev_build.sh)")
     common = [_hipcc(), "-O3", "-std=c++17", "-ffp-contract=off", "--offload-arch=gfx950", "-fPIC",
               "-DTFHE_WAVES_PER_SIMD_FP=2", "-DTFHE_WAVES_PER_SIMD_GL=2",
               "-I", os.path.join(ROOT, "include"), "-I", CSRC] + list(extra)

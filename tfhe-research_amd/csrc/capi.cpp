@@ -259,7 +259,34 @@ int adopt_prepared_key(tfhe_context* dst, const tfhe_context* src) {
 
 extern "C" {
 
-const char* tfhe_version(void) { return "tfhe-research_amd 0.4 (gfx950; exact backends: fp64-fft, fp64-p49, fp64-p42, goldilocks, goldilocks-split)"; }
+// The shipped library's string carries no '[': a dev build (TFHE_DEV_BUILD: the only kind that may compile a WRONG-BITS
+// timing probe in, csrc/dev_switches.h), the rounding-margin probe build and one-shape / one-field builds all say so.
+const char* tfhe_version(void) {
+  return "tfhe-research_amd 0.5 (gfx950; exact backends: fp64-fft, fp64-p49, fp64-p42, goldilocks, goldilocks-split)"
+#if defined(TFHE_DEV_BUILD)
+         " [DEV BUILD: not for use"
+#if TFHE_PROBE_HOT_KEY
+         "; WRONG BITS: TFHE_PROBE_HOT_KEY"
+#endif
+#if TFHE_PROBE_NO_EXCHANGE_READS
+         "; WRONG BITS: TFHE_PROBE_NO_EXCHANGE_READS"
+#endif
+#if TFHE_PROBE_NO_TRANSPOSE
+         "; WRONG BITS: TFHE_PROBE_NO_TRANSPOSE"
+#endif
+#if TFHE_PROBE_NO_TEAM_SYNC
+         "; WRONG BITS: TFHE_PROBE_NO_TEAM_SYNC"
+#endif
+         "]"
+#endif
+#if defined(TFHE_FFT_TRACK_ERROR)
+         " [probe build: fp64-fft rounding margin tracked]"
+#endif
+#if defined(TFHE_DEV_CFG2_ONLY) || defined(TFHE_DEV_FIELD_FP_ONLY) || defined(TFHE_DEV_FIELD_FP49_ONLY) || defined(TFHE_DEV_FIELD_FFT_ONLY)
+         " [subset build: not every shape / backend]"
+#endif
+      ;
+}
 
 const char* tfhe_status_string(int status) {
   switch (status) {
@@ -571,6 +598,17 @@ int tfhe_debug_blind_rotate_plan(tfhe_context* ctx, size_t batch, size_t* sample
   *segments = ctx->bmmp ? 1u : plan.segments;
   *streams = ctx->bmmp ? 1u : (unsigned)plan.streams;
   *resident_samples = plan.resident_samples;
+  return TFHE_OK;
+}
+
+int tfhe_debug_blind_rotate_shape(tfhe_context* ctx, size_t batch, unsigned* waves_per_sample, unsigned* samples_per_team) {
+  int st = check_ctx(ctx);
+  if (st) return st;
+  if (!waves_per_sample || !samples_per_team) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer");
+  launch::BlindRotatePlanInfo plan{};
+  HIP_TRY(ctx, launch::blind_rotate_plan(ctx->field, ctx->pbs, batch, !ctx->bmmp, ctx->side.stream != nullptr, &plan));
+  *waves_per_sample = (unsigned)plan.waves_per_sample;
+  *samples_per_team = (unsigned)plan.samples_per_team;
   return TFHE_OK;
 }
 

@@ -9,7 +9,6 @@
 #include <cstdlib>
 
 #include "launch.h"
-#include "pbs_split.h"
 
 namespace tfhe {
 namespace {
@@ -119,10 +118,7 @@ struct DeviceWave {
   // 8 barriers that only order a group's cross-wave transposes was built and measured: bit-exact, same
   // time (78.88 vs 78.95 ms) -- the wait is the drift between waves that share SIMDs three at a time,
   // whatever the scope.  profiles/r02_kernel_ab.txt)
-  // (TFHE_PROBE_NO_TEAM_SYNC: timing probe, WRONG BITS -- the team barriers compiled out.  Dev builds only.)
-#ifndef TFHE_PROBE_NO_TEAM_SYNC
-#define TFHE_PROBE_NO_TEAM_SYNC 0
-#endif
+  // (TFHE_PROBE_NO_TEAM_SYNC: dev_switches.h -- a WRONG-BITS timing probe, TFHE_DEV_BUILD only)
   __device__ __forceinline__ void team_sync() const {
     if (!TFHE_PROBE_NO_TEAM_SYNC) __syncthreads();
   }
@@ -282,7 +278,8 @@ __global__ void __launch_bounds__((TeamCfg<F, LOGN, K>::kThreads),
 blind_rotate_kernel(PbsParams P, const typename F::elem* __restrict__ tw,
                     const u32* __restrict__ lwe_in, size_t batch, const u32* __restrict__ tv,
                     size_t tv_stride, const typename F::elem* __restrict__ bsk,
-                    u32* __restrict__ glwe_out, u32* __restrict__ lwe_extracted,
+                    u32* glwe_out /* may be glwe_state (the caller's output parks the accumulators): no restrict */,
+                    u32* __restrict__ lwe_extracted,
                     u32 i_begin, u32 i_end, u32* glwe_state /* [batch][K+1][N]: accumulators between segments */) {
   using C = TeamCfg<F, LOGN, K>;
   constexpr int N = C::N;
@@ -318,7 +315,7 @@ blind_rotate_kernel(PbsParams P, const typename F::elem* __restrict__ tw,
   }
   const u32* resume[NS];
 #pragma unroll
-  for (int s = 0; s < NS; ++s) resume[s] = glwe_state + sample[s] * (size_t)(K + 1) * N;
+  for (int s = 0; s < NS; ++s) resume[s] = i_begin > 0 ? glwe_state + sample[s] * (size_t)(K + 1) * N : nullptr;  // (null state: one launch)
   blind_rotate_team_multi<F, LOGN, K, G, NS>(w, P, lwes, tvs, bsk, i_begin, i_end, resume);
 
   const int tid = w.tid();
@@ -344,72 +341,106 @@ blind_rotate_kernel(PbsParams P, const typename F::elem* __restrict__ tw,
   }
 }
 
-// ------------------------------------------------------------------------------ EXPERIMENT: split-part team (pbs_split.h)
-#ifndef TFHE_SPLIT_N1024
-#define TFHE_SPLIT_N1024 0
-#endif
-// LDS: [ twiddles ][ group g = 2 c + q: exchange buffer N x 8 B | accumulator polynomial (c, sample q) N x 4 B ], g < 2 (K + 1)
-template <class F, int LOGN, int K>
-struct SplitCfg {
-  static constexpr int N = 1 << LOGN;
-  static constexpr int kGroups = 2 * (K + 1);
-  static constexpr int kThreads = kGroups * 64;
-  static constexpr unsigned kGroupLds = (unsigned)N * 8u + (unsigned)N * 4u;
-  static constexpr size_t kTwBytes = (size_t)staged_twiddle_words<F, LOGN>() * sizeof(typename F::elem);
-  static constexpr size_t kLds = kTwBytes + (size_t)kGroups * kGroupLds;
+// ------------------------------------------------------------------------------ blind rotation, wide team
+// The latency shape (pbs_wave.h::blind_rotate_team_wide): 2 (K+1) waves per sample -- wave (c, q) transforms half of
+// polynomial c's digit levels, accumulates key part q of column c over all rows and inverse-transforms that one
+// accumulator.  The complex transform up to N = 1024.  Picked by the launcher for batches that leave most CUs idle.
+// LDS: [ twiddles ][ RB row buffers of N x 8 B ][ K+1 accumulator polynomials of N x 4 B ], RB = max((K+1) l, 2 (K+1))
+template <class Elem>
+struct WideWave {
+  unsigned char* rows_;  // row buffer 0
+  Elem* scratch_;        // the row buffer this copy transposes in
+  u32* acc_;             // my polynomial's accumulator
+  const Elem* tw_;
+  const Elem* twg_;
+  unsigned row_bytes_;
+  int wave_;             // 2 c + q
+  __device__ __forceinline__ int tid() const { return (int)(threadIdx.x & 63u); }
+  __device__ __forceinline__ int group() const { return wave_ >> 1; }
+  __device__ __forceinline__ int half() const { return wave_ & 1; }
+  __device__ __forceinline__ int wave_index() const { return wave_; }
+  __device__ __forceinline__ WideWave with_row(int r) const {
+    WideWave w = *this;
+    w.scratch_ = reinterpret_cast<Elem*>(rows_ + (size_t)r * row_bytes_);
+    return w;
+  }
+  __device__ __forceinline__ const Elem* row_buffer(int r) const { return reinterpret_cast<const Elem*>(rows_ + (size_t)r * row_bytes_); }
+  __device__ __forceinline__ void wave_sync() const {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  __device__ __forceinline__ void poly_sync() const { wave_sync(); }  // one wave per transform
+  __device__ __forceinline__ void team_sync() const { __syncthreads(); }
+  __device__ __forceinline__ Elem* scratch() const { return scratch_; }
+  __device__ __forceinline__ u32* acc(int = 0) const { return acc_; }
+  __device__ __forceinline__ const Elem* twiddles() const { return tw_; }
+  __device__ __forceinline__ const Elem* twiddles_uniform() const { return twg_; }
+  __device__ __forceinline__ u32 uniform(u32 v) const { return __builtin_amdgcn_readfirstlane(v); }
+  __device__ __forceinline__ void lds_add(u32* p, u32 v) const {
+    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  __device__ __forceinline__ void compiler_fence() const { asm volatile("" ::: "memory"); }
 };
 
 template <class F, int LOGN, int K>
-__global__ void __launch_bounds__((SplitCfg<F, LOGN, K>::kThreads), 2)
-blind_rotate_split_kernel(PbsParams P, const typename F::elem* __restrict__ tw, const u32* __restrict__ lwe_in, size_t batch,
-                          const u32* __restrict__ tv, size_t tv_stride, const typename F::elem* __restrict__ bsk,
-                          u32* __restrict__ glwe_out, u32* __restrict__ lwe_extracted) {
+struct WideCfg {
+  static constexpr int N = 1 << LOGN;
+  static constexpr int kWaves = 2 * (K + 1);
+  static constexpr int kThreads = kWaves * 64;
+  static constexpr size_t kTwBytes = (size_t)staged_twiddle_words<F, LOGN>() * sizeof(typename F::elem);
+  static constexpr unsigned kRowBytes = (unsigned)N * 8u;
+  static __host__ __device__ size_t row_buffers(u32 levels) { return (size_t)(K + 1) * (levels > 2u ? levels : 2u); }
+  static __host__ __device__ size_t lds(u32 levels) { return kTwBytes + row_buffers(levels) * kRowBytes + (size_t)(K + 1) * N * 4; }
+};
+
+template <class F, int LOGN, int K>
+__global__ void __launch_bounds__((WideCfg<F, LOGN, K>::kThreads), 1)
+blind_rotate_wide_kernel(PbsParams P, const typename F::elem* __restrict__ tw, const u32* __restrict__ lwe_in, size_t batch,
+                         const u32* __restrict__ tv, size_t tv_stride, const typename F::elem* __restrict__ bsk,
+                         u32* glwe_out, u32* __restrict__ lwe_extracted, u32 i_begin, u32 i_end, u32* glwe_state) {
   typedef typename F::elem elem;
-  using C = SplitCfg<F, LOGN, K>;
+  using C = WideCfg<F, LOGN, K>;
   constexpr int N = C::N;
-  constexpr int E = NttShape<LOGN, 1>::kE;
+  constexpr int EC = N / 64;
   elem* twl = reinterpret_cast<elem*>(g_smem);
   ntt_stage_twiddles<LOGN - F::kLogShrink, 1, elem, staged_twiddle_words<F, LOGN>()>(twl, tw, (int)threadIdx.x, (int)blockDim.x);
   __syncthreads();
-  DeviceWave<elem, 1, 1> w;
-  w.group_ = (int)(threadIdx.x / 64u);
-  w.group_stride_ = C::kGroupLds;
-  w.buffer_bytes_ = (unsigned)N * 8u;
-  w.team_base_ = g_smem + C::kTwBytes;
+  WideWave<elem> w;
+  w.wave_ = (int)(threadIdx.x >> 6);
+  w.rows_ = g_smem + C::kTwBytes;
+  w.row_bytes_ = C::kRowBytes;
+  w.scratch_ = reinterpret_cast<elem*>(w.rows_ + (size_t)w.wave_ * C::kRowBytes);
+  w.acc_ = reinterpret_cast<u32*>(w.rows_ + C::row_buffers(P.levels) * C::kRowBytes) + (size_t)w.group() * N;
   w.tw_ = twl;
   w.twg_ = tw;
-  w.scratch_ = reinterpret_cast<elem*>(w.team_base_ + (size_t)w.group_ * C::kGroupLds);
-  // acc(s): accumulator polynomial (group >> 1) of sample s lives in the region of group 2 (group >> 1) + s
-  w.acc_ = reinterpret_cast<u32*>(w.team_base_ + (size_t)(w.group_ & ~1) * C::kGroupLds + (size_t)N * 8);
-  w.acc_words_ = C::kGroupLds / 4u;
-  size_t sample[2];
-  const u32* lwes[2];
-  const u32* tvs[2];
+  const size_t sample = blockIdx.x;  // grid = batch
+  const u32* resume = i_begin > 0 ? glwe_state + sample * (size_t)(K + 1) * N : nullptr;
+  blind_rotate_team_wide<F, LOGN, K>(w, P, lwe_in + sample * (P.n + 1), tv + sample * tv_stride, bsk, i_begin, i_end, resume);
+  (void)batch;
+  // each half stores the words it loaded: registers [q EC/2, (q + 1) EC/2) of polynomial c
+  const int tid = w.tid(), me = w.group(), q = w.half();
+  const u32* acc = w.acc();
+  if (i_end < P.n) {  // not the last segment: park the accumulators
+    u32* dst = glwe_state + (sample * (size_t)(K + 1) + me) * N;
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const size_t idx = (size_t)blockIdx.x * 2 + s;
-    sample[s] = idx < batch ? idx : batch - 1;
-    lwes[s] = lwe_in + sample[s] * (P.n + 1);
-    tvs[s] = tv + sample[s] * tv_stride;
+    for (int r = 0; r < EC / 2; ++r) dst[(r + q * (EC / 2)) * 64 + tid] = acc[(r + q * (EC / 2)) * 64 + tid];
+    return;
   }
-  blind_rotate_team_split<F, LOGN, K>(w, P, lwes, tvs, bsk);
-  const int me = w.group_ >> 1, mine = w.group_ & 1, tid = w.tid();
-  if ((size_t)blockIdx.x * 2 + mine >= batch) return;  // the duplicate of an odd batch's last sample
-  const u32* acc = w.acc(mine);
   if (glwe_out) {
-    u32* dst = glwe_out + (sample[mine] * (size_t)(K + 1) + me) * N;
+    u32* dst = glwe_out + (sample * (size_t)(K + 1) + me) * N;
 #pragma unroll
-    for (int r = 0; r < E; ++r) dst[r * 64 + tid] = acc[r * 64 + tid];
+    for (int r = 0; r < EC / 2; ++r) dst[(r + q * (EC / 2)) * 64 + tid] = acc[(r + q * (EC / 2)) * 64 + tid];
   }
-  if (lwe_extracted) {  // sample_extract at index 0 (bootstrapping.rs:122-156)
-    u32* out = lwe_extracted + sample[mine] * ((size_t)K * N + 1);
+  if (lwe_extracted) {  // sample_extract at index 0 (bootstrapping.rs:122-156), the words split between the halves
+    u32* out = lwe_extracted + sample * ((size_t)K * N + 1);
     if (me < K) {
 #pragma unroll
-      for (int r = 0; r < E; ++r) {
-        const int x = r * 64 + tid;
+      for (int r = 0; r < EC / 2; ++r) {
+        const int x = (r + q * (EC / 2)) * 64 + tid;
         out[me * N + x] = (x == 0) ? acc[0] : (0u - acc[N - x]);
       }
-    } else if (tid == 0) {
+    } else if (q == 0 && tid == 0) {
       out[K * N] = acc[0];
     }
   }
@@ -942,25 +973,75 @@ inline BlindRotatePlan blind_rotate_plan(size_t batch, bool can_park, bool have_
   return plan;
 }
 
-// teams of blind_rotate_kernel<F, LOGN, K> the chip holds at once (occupancy x CUs), asked once per instantiation
+// teams of blind_rotate_kernel<F, LOGN, K> the CURRENT device holds at once (occupancy x CUs), asked once per
+// instantiation and device (a pool spans devices: nothing about one device is assumed of another)
+constexpr int kMaxDevices = 64;
+inline int current_device_slot() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+  return dev;
+}
 template <class F, int LOGN, int K>
 hipError_t resident_teams(unsigned* out) {
   using C = TeamCfg<F, LOGN, K>;
-  static std::atomic<unsigned> cached{0};
-  unsigned capacity = cached.load(std::memory_order_acquire);
+  static std::atomic<unsigned> cached[kMaxDevices];
+  const int dev = current_device_slot();
+  unsigned capacity = cached[dev].load(std::memory_order_acquire);
   if (capacity == 0) {
     auto kern = blind_rotate_kernel<F, LOGN, K>;
-    int per_cu = 0, dev = 0, cus = 0;
+    int per_cu = 0, cus = 0;
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, C::kThreads, C::kLds);
     if (e != hipSuccess) return e;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-      cus = 256;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
     capacity = (unsigned)(per_cu > 0 ? per_cu : 1) * (unsigned)(cus > 0 ? cus : 256);
-    cached.store(capacity, std::memory_order_release);
+    cached[dev].store(capacity, std::memory_order_release);
   }
   *out = capacity;
   return hipSuccess;
+}
+
+// The wide team (blind_rotate_wide_kernel) is offered for the complex transform up to N = 1024 while its row buffers fit
+// the CU's LDS; it is USED for batches up to `wide_max_batch`: below that the chip has CUs to spare and a sample's latency
+// -- not the chip's throughput -- is what a caller waits for (profiles/r04_batch_sweep*.txt).  TFHE_BR_WIDE overrides the
+// threshold (0: never; n: batches up to n).
+template <class F, int LOGN, int K>
+constexpr bool wide_shape_ok() {
+  return F::kLogShrink == 1 && F::kParts == 2 && LOGN <= 10 && field_shape_ok<F, LOGN>();
+}
+template <class F, int LOGN, int K>
+size_t wide_max_batch(const PbsParams& P) {
+  if constexpr (!wide_shape_ok<F, LOGN, K>()) {
+    return 0;
+  } else {
+    using W = WideCfg<F, LOGN, K>;
+    if (W::lds(P.levels) > (size_t)160 * 1024) return 0;
+    static const long env_wide = std::getenv("TFHE_BR_WIDE") ? std::atol(std::getenv("TFHE_BR_WIDE")) : -1;
+    if (env_wide >= 0) return (size_t)env_wide;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, current_device_slot()) != hipSuccess || cus <= 0) cus = 256;
+#ifndef TFHE_WIDE_BATCH_PER_CU
+#define TFHE_WIDE_BATCH_PER_CU 1
+#endif
+    return (size_t)cus * TFHE_WIDE_BATCH_PER_CU;
+  }
+}
+
+template <class F, int LOGN, int K>
+hipError_t launch_blind_rotate_wide(hipStream_t s, const PbsParams& P, const typename F::elem* tw, const u32* lwe_in, size_t batch,
+                                    const u32* tv, size_t tv_stride, const typename F::elem* bsk, u32* glwe_out,
+                                    u32* lwe_extracted) {
+  if constexpr (!wide_shape_ok<F, LOGN, K>()) {
+    return hipErrorInvalidValue;
+  } else {
+    using W = WideCfg<F, LOGN, K>;
+    auto kern = blind_rotate_wide_kernel<F, LOGN, K>;
+    static std::atomic<unsigned long long> lds_done{0};
+    hipError_t e = allow_lds(kern, (size_t)160 * 1024, lds_done);  // the size depends on the level count: allow the CU's whole LDS
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(W::kThreads), W::lds(P.levels), s, P, tw, lwe_in, batch, tv, tv_stride,
+                       bsk, glwe_out, lwe_extracted, 0u, P.n, static_cast<u32*>(nullptr));
+    return hipGetLastError();
+  }
 }
 
 template <class F, int LOGN, int K>
@@ -981,6 +1062,14 @@ hipError_t plan_blind_rotate(const PbsParams& P, size_t batch, bool can_park, bo
     out->streams = plan.streams == 2 && plan.segments > 1 ? 2 : 1;
     out->resident_samples = (size_t)capacity * C::S;
     out->samples_per_team = C::S;
+    out->waves_per_sample = C::kWaves;
+    if (batch > 0 && batch <= wide_max_batch<F, LOGN, K>(P)) {  // the wide team: one launch over the whole key
+      out->chunk = batch;
+      out->segments = 1;
+      out->streams = 1;
+      out->samples_per_team = 1;
+      out->waves_per_sample = 2 * (K + 1);
+    }
     return hipSuccess;
   }
 }
@@ -995,23 +1084,9 @@ hipError_t launch_blind_rotate(hipStream_t s, const PbsParams& P, const void* tw
     using C = TeamCfg<F, LOGN, K>;
     auto tw = static_cast<const typename F::elem*>(tw_v);
     auto bsk = static_cast<const typename F::elem*>(bsk_v);
-    if constexpr (TFHE_SPLIT_N1024 && F::kLogShrink == 1 && LOGN == 10) {  // EXPERIMENT: pbs_split.h
-      using SC = SplitCfg<F, LOGN, K>;
-      auto skern = blind_rotate_split_kernel<F, LOGN, K>;
-      static std::atomic<unsigned long long> split_lds_done{0};
-      hipError_t se = allow_lds(skern, SC::kLds, split_lds_done);
-      if (se != hipSuccess) return se;
-      const size_t schunk = 4096;
-      for (size_t off = 0; off < batch; off += schunk) {
-        const size_t here = batch - off < schunk ? batch - off : schunk;
-        hipLaunchKernelGGL(skern, dim3((unsigned)((here + 1) / 2)), dim3(SC::kThreads), SC::kLds, s, P, tw,
-                           lwe_in + off * ((size_t)P.n + 1), here, tv + off * tv_stride, tv_stride, bsk,
-                           glwe_out ? glwe_out + off * (size_t)(K + 1) * SC::N : nullptr,
-                           lwe_extracted ? lwe_extracted + off * ((size_t)K * SC::N + 1) : nullptr);
-        se = hipGetLastError();
-        if (se != hipSuccess) return se;
-      }
-      return hipSuccess;
+    if constexpr (wide_shape_ok<F, LOGN, K>()) {
+      if (batch <= wide_max_batch<F, LOGN, K>(P))
+        return launch_blind_rotate_wide<F, LOGN, K>(s, P, tw, lwe_in, batch, tv, tv_stride, bsk, glwe_out, lwe_extracted);
     }
     auto kern = blind_rotate_kernel<F, LOGN, K>;
     static std::atomic<unsigned long long> lds_done{0};
@@ -1100,12 +1175,13 @@ hipError_t launch_external_product(hipStream_t s, const PbsParams& P, const void
     hipError_t e = allow_lds(kern, kLdsWithTicket, lds_done);
     if (e != hipSuccess) return e;
     // persistent grid: as many teams as the device keeps resident at once (LDS or registers decide)
-    static std::atomic<int> resident{0};
+    static std::atomic<int> resident_per_device[kMaxDevices];
+    const int dev_slot = current_device_slot();
+    std::atomic<int>& resident = resident_per_device[dev_slot];
     int teams = resident.load(std::memory_order_relaxed);
     if (teams == 0) {
-      int dev = 0, cus = 0, per_cu = 0;
-      e = hipGetDevice(&dev);
-      if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      int dev = dev_slot, cus = 0, per_cu = 0;
+      e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
       if (e == hipSuccess)
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), C::kThreads, kLdsWithTicket);
       if (e != hipSuccess) return e;

@@ -52,6 +52,7 @@ struct BlindRotatePlanInfo {
   int streams;              // 1 or 2
   size_t resident_samples;  // samples the chip rotates at once (teams it holds x samples per team)
   int samples_per_team;
+  int waves_per_sample;     // K+1 groups of G waves (shared by samples_per_team samples), or 2 (K+1) for the wide team
 };
 hipError_t blind_rotate_plan(int field, const PbsParams& P, size_t batch, bool can_park, bool have_side,
                              BlindRotatePlanInfo* out);

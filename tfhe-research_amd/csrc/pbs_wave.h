@@ -237,11 +237,7 @@ TFHE_HD void external_product_team_multi(const Ctx& c, const PbsParams& P, const
   constexpr int CH = E < CH_MAX ? E : CH_MAX;
   constexpr int CHUNKS = TILES * (E / CH);
   // tile of source polynomial sp and accumulator a = (key m, part q)
-  // (TFHE_PROBE_HOT_KEY: timing probe, WRONG BITS -- every key chunk is read from the first 4 KiB of the key, i.e. from
-  // the vector L1: what is left is the kernel without its key stream.  Dev builds only, never the shipped library.)
-#ifndef TFHE_PROBE_HOT_KEY
-#define TFHE_PROBE_HOT_KEY 0
-#endif
+  // (TFHE_PROBE_HOT_KEY: dev_switches.h -- a WRONG-BITS timing probe, TFHE_DEV_BUILD only)
   auto tile_ptr = [&](u32 level, int sp, int a) -> const elem* {
     const int m = a / PARTS, q = a % PARTS;
     if (TFHE_PROBE_HOT_KEY) return ggsw;
@@ -401,10 +397,7 @@ TFHE_HD void external_product_team_multi(const Ctx& c, const PbsParams& P, const
       constexpr int cur = ci % NB;
       if constexpr (OWN && ci == ACCS * PIECES) c.team_sync();  // my own spectrum is done with: now the others'
       if constexpr (ci + NB - 1 < CHUNKS) load_chunk(level, IntC<ci + NB - 1>{}, (ci + NB - 1) % NB);
-      // (TFHE_PROBE_NO_EXCHANGE_READS: timing probe, WRONG BITS -- the digit spectra are not read back from LDS.)
-#ifndef TFHE_PROBE_NO_EXCHANGE_READS
-#define TFHE_PROBE_NO_EXCHANGE_READS 0
-#endif
+      // (TFHE_PROBE_NO_EXCHANGE_READS: dev_switches.h -- a WRONG-BITS timing probe, TFHE_DEV_BUILD only)
       if constexpr (OWN_REGS && sp == 0) {
         if constexpr (q == 0) {
 #pragma unroll
@@ -621,6 +614,182 @@ TFHE_HD void blind_rotate_team(const Ctx& c, const PbsParams& P, const u32* lwe 
   const u32* const lwes[1] = {lwe};
   const u32* const tvs[1] = {tv};
   blind_rotate_team_multi<F, LOGN, K, G, 1>(c, P, lwes, tvs, bsk);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The WIDE team: the latency shape for batches that leave most of the chip idle (the reference's own call
+// shape is ONE ciphertext per bootstrap(), bootstrapping.rs:58-65, one pair per gate, boolean.rs:9-37).
+//
+// A team of K+1 waves serialises, per CMUX, `levels` forward transforms, (K+1) levels kParts multiply-accumulate
+// tiles and kParts inverse transforms in every wave.  The wide team spends kParts = 2 waves per polynomial and
+// splits that chain by LEVEL and by KEY PART instead of by coefficient (no extra register pass, no cross-wave
+// transpose): wave (c, q), c = polynomial / output column, q = half,
+//   - reads and rounds X^a acc_c - acc_c like its twin (16 words per lane: cheap to do twice) and runs the digit
+//     chain from the lowest limb, but forward-transforms only ITS levels -- the lower ceil(l/2) limbs for q = 0,
+//     the upper ones for q = 1 -- each in the LDS buffer of its digit row (row = c l + level), where the
+//     spectrum then stays published;
+//   - barrier A: all (K+1) l digit spectra are visible;
+//   - accumulates key part q of column c over ALL rows (half the tiles of a one-wave-per-polynomial team);
+//   - barrier B: nobody reads a spectrum any more, the buffers are free;
+//   - inverse-transforms its one accumulator (in buffer number 2c + q) and adds lift(part q) << 16 q to the
+//     accumulator polynomial with ds_add_u32 -- wrapping addition commutes, so the two halves of a column need
+//     no order: acc_c += t_lo + 2^16 t_hi mod 2^32 exactly as FftField::finish forms it.
+// Per wave and CMUX at N = 1024, k = 1, l = 3: 2 (or 1) forward transforms, 6 tiles, 1 inverse transform instead
+// of 3, 12 and 2.  The same exact integer sums in another order: same bits (field_fft.h: the rounding bound does
+// not depend on the order of the rows).  Needs max((K+1) l, 2 (K+1)) buffers of N x 8 bytes in LDS: offered up to
+// N = 1024.  Three team barriers per CMUX.
+//
+// Ctx additionally provides: half() (q), wave_index() (2c + q), with_row(r): a copy whose scratch() is row buffer r,
+// row_buffer(r): that buffer for reading.
+// ---------------------------------------------------------------------------------------------
+template <class F, int LOGN, int K, class Ctx, class Src, class Out>
+TFHE_HD void external_product_team_wide(const Ctx& c, const PbsParams& P, const typename F::elem* ggsw, Src src, Out out) {
+  typedef typename F::elem elem;
+  static_assert(F::kParts == 2 && F::kLogShrink == 1 && F::kCoeffs == 2, "the complex transform: two key parts, two coefficients per element");
+  constexpr int LT = LOGN - 1;
+  constexpr int E = NttShape<LT, 1>::kE;
+  constexpr int EC = 2 * E;
+  constexpr int T = 64;
+  constexpr int N = 1 << LT;  // transform elements per polynomial
+  const int lane = c.tid();
+  const int me = c.group();
+  const int q = c.half();
+  // levels counted from the least significant limb (t), as the digit chain runs; level index = levels - 1 - t
+  const u32 split = (P.levels + 1u) / 2u;
+  const u32 t_begin = q == 0 ? 0u : split, t_end = q == 0 ? split : P.levels;
+
+  TopConsts<F, LT, 1, true> ftop;
+  ftop.issue(c.twiddles_uniform());
+  u32 v[EC];
+  const RoundConsts rc = round_consts(P.ignored_bits);
+#pragma unroll
+  for (int r = 0; r < EC; ++r) v[r] = round_value_fast(src(r * T + lane), rc);
+  ftop.ready();
+
+  // key chunks of my (column, part): row by row, CH elements at a time, double-buffered in registers
+  // (an even number of chunks per level keeps the staging buffer of a chunk a compile-time constant across levels)
+  constexpr int CH0 = E < 4 ? E : 4;
+  constexpr int CH = (((K + 1) * (E / CH0)) % 2 == 0) ? CH0 : CH0 / 2;
+  constexpr int PIECES = E / CH;
+  constexpr int CHK = (K + 1) * PIECES;  // chunks per level: source polynomial sp, then the piece of its spectrum
+  elem kbuf[2][CH];
+  auto load_chunk = [&](u32 level, auto ci_c, int buf) {
+    constexpr int ci = decltype(ci_c)::value;
+    constexpr int sp = ci / PIECES, r0 = (ci % PIECES) * CH;
+    const elem* tile = ggsw + ((((size_t)sp * P.levels + level) * (K + 1) + me) * 2 + q) * N;
+#pragma unroll
+    for (int r = 0; r < CH; ++r) kbuf[buf][r] = tile[spectrum_slot<LT, 1, (int)sizeof(elem)>(lane, r0 + r)];
+  };
+  load_chunk(0u, IntC<0>{}, 0);  // in flight under the forward transforms
+  c.compiler_fence();
+
+#pragma unroll 1
+  for (u32 t = 0; t < t_end; ++t) {
+    const u32 shift = P.first_shift + P.log_base * t;
+    const u32 carry_width = (t == 0) ? 0u : 1u;
+    elem work[E];
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+      u32 dg[2];
+      dg[0] = decompose_limb_fast<true>(v[r], shift, P.log_base, carry_width);
+      dg[1] = decompose_limb_fast<true>(v[r + E], shift, P.log_base, carry_width);
+      work[r] = F::from_digits(dg);
+    }
+    if (t < t_begin) continue;  // (wave-uniform) my twin's limb: only the carries were needed
+    const u32 row = (u32)me * P.levels + (P.levels - 1u - t);
+    const Ctx cr = c.with_row((int)row);
+    // (nobody has touched the row buffers since barrier C of the previous product)
+    ntt_forward<F, LT, 1, true, true>(cr, work, ftop);
+    elem* mine = cr.scratch();
+#pragma unroll
+    for (int r = 0; r < E; ++r) mine[exchange_slot<LT, 1>(lane, r)] = work[r];
+  }
+  TopConsts<F, LT, 1, false> itop;  // arrives under the multiply-accumulate
+  itop.issue(c.twiddles_uniform());
+  c.team_sync();  // A: every digit spectrum is published
+
+  elem accum[E];
+#pragma unroll
+  for (int r = 0; r < E; ++r) accum[r] = F::zero();
+#pragma unroll 1
+  for (u32 level = 0; level < P.levels; ++level) {
+    static_for<0, CHK>([&](auto ci_c) {
+      constexpr int ci = decltype(ci_c)::value;
+      constexpr int sp = ci / PIECES, r0 = (ci % PIECES) * CH;
+      constexpr int cur = ci % 2;
+      static_assert(CHK % 2 == 0, "an even number of chunks per level keeps the buffer parity static");
+      if constexpr (ci + 1 < CHK) {
+        load_chunk(level, IntC<ci + 1>{}, (ci + 1) % 2);
+      } else {
+        if (level + 1u < P.levels) load_chunk(level + 1u, IntC<0>{}, 0);
+      }
+      const elem* spec = c.row_buffer((int)((u32)sp * P.levels + level));
+      elem d[CH];
+#pragma unroll
+      for (int r = 0; r < CH; ++r) d[r] = spec[exchange_slot<LT, 1>(lane, r0 + r)];
+      c.compiler_fence();  // keep the next chunk's loads above this chunk's arithmetic
+#pragma unroll
+      for (int r = 0; r < CH; ++r) accum[r0 + r] = F::mul_add(d[r], kbuf[cur][r], accum[r0 + r]);
+    });
+  }
+  c.team_sync();  // B: the spectra are done with; any buffer may be written again
+
+#pragma unroll
+  for (int r = 0; r < E; ++r) accum[r] = F::before_inverse(accum[r]);
+  itop.ready();
+  const Ctx ci = c.with_row(c.wave_index());
+  ntt_inverse<F, LT, 1>(ci, accum, itop);
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    out(q, r * T + lane, F::to_u32(accum[r].re));
+    out(q, (r + E) * T + lane, F::to_u32(accum[r].im));
+  }
+}
+
+// Blind rotation of ONE sample by a wide team (bootstrapping.rs:67-105); segments as blind_rotate_team_multi.
+template <class F, int LOGN, int K, class Ctx>
+TFHE_HD void blind_rotate_team_wide(const Ctx& c, const PbsParams& P, const u32* lwe /* n+1 */, const u32* tv /* N, un-encoded */,
+                                    const typename F::elem* bsk /* prepared */, u32 i_begin, u32 i_end,
+                                    const u32* resume /* [K+1][N], read if i_begin > 0 */) {
+  constexpr int N = 1 << LOGN;
+  constexpr int EC = N / 64;  // accumulator words per lane
+  const int lane = c.tid();
+  const int me = c.group();
+  const int q = c.half();
+  u32* acc = c.acc();
+  // each half fills (and, in the kernel's epilogue, stores) half of the polynomial's words: registers [q EC/2, (q+1) EC/2)
+  if (i_begin > 0) {
+    const u32* from = resume + (size_t)me * N;
+#pragma unroll
+    for (int r = 0; r < EC / 2; ++r) acc[(r + q * (EC / 2)) * 64 + lane] = from[(r + q * (EC / 2)) * 64 + lane];
+  } else {
+    // acc = X^{-b~} * (0, ..., 0, tv << tv_shift)
+    const u32 b_tilde = switch_modulus_2n(lwe[P.n], LOGN);
+    const u32 m = (2u * N - b_tilde) & (2u * N - 1u);
+    const int deg = (int)(m & (N - 1));
+    const u32 flip = (m >> LOGN) & 1u;
+#pragma unroll
+    for (int r = 0; r < EC / 2; ++r) {
+      const int j = (r + q * (EC / 2)) * 64 + lane;
+      u32 val = 0;
+      if (me == K) {
+        const u32 t = tv[(j - deg) & (N - 1)] << P.tv_shift;
+        val = (flip ^ (u32)(j < deg)) ? (0u - t) : t;
+      }
+      acc[j] = val;
+    }
+  }
+  c.team_sync();
+  const size_t ggsw_words = (size_t)(K + 1) * P.levels * (K + 1) * 2 * (N >> 1);  // elements
+#pragma unroll 1
+  for (u32 i = i_begin; i < i_end; ++i) {
+    const u32 a_tilde = c.uniform(switch_modulus_2n(lwe[i], LOGN));
+    auto src = [&](int j) -> u32 { return monomial_coeff<LOGN>(acc, j, a_tilde) - acc[j]; };
+    // every rotated read of acc happens before barrier A, every update after barrier B: in place is safe
+    auto out = [&](int half, int j, u32 value) { c.lds_add(acc + j, value << (16 * half)); };
+    external_product_team_wide<F, LOGN, K>(c, P, bsk + (size_t)i * ggsw_words, src, out);
+    c.team_sync();  // C: both halves of every column have added their part
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

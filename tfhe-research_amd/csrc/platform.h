@@ -4,6 +4,8 @@
 #pragma once
 #include <stdint.h>
 
+#include "dev_switches.h"
+
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define TFHE_HD __host__ __device__ __forceinline__

@@ -43,22 +43,33 @@ void shard(size_t batch, size_t n, size_t i, size_t* first, size_t* count) {
   *count = base + (i < extra ? 1 : 0);
 }
 
-// run fn(member index) for every member with work on its own host thread; the first failing member's status wins
+// run fn(member index) for every member with work on its own host thread; the first failing member's status wins.
+// Nothing may propagate out of an extern "C" entry point: if a thread cannot be started (EAGAIN, bad_alloc) that
+// member's slice runs inline on the calling thread instead, and whatever was started is joined before returning.
 template <class Fn>
 int for_members(tfhe_pool* pool, size_t batch, Fn fn) {
   const size_t n = pool->members.size();
   std::vector<int> status(n, TFHE_OK);
   std::vector<std::thread> threads;
-  threads.reserve(n);
+  try {
+    threads.reserve(n);
+  } catch (...) {
+    return pool_fail(pool, TFHE_ERR_HIP, "out of host memory");
+  }
   for (size_t i = 0; i < n; ++i) {
     size_t first, count;
     shard(batch, n, i, &first, &count);
     if (count == 0) continue;
-    if (n == 1) {
-      status[i] = fn(i, first, count);
-    } else {
-      threads.emplace_back([&status, &fn, i, first, count] { status[i] = fn(i, first, count); });
+    bool started = false;
+    if (n > 1) {
+      try {
+        threads.emplace_back([&status, &fn, i, first, count] { status[i] = fn(i, first, count); });
+        started = true;
+      } catch (...) {
+        started = false;  // no thread to be had: this member's slice runs here
+      }
     }
+    if (!started) status[i] = fn(i, first, count);
   }
   for (auto& t : threads) t.join();
   for (size_t i = 0; i < n; ++i)
@@ -157,6 +168,33 @@ static int replicate_from_member0(tfhe_pool* pool) {
   return tfhe_pool_synchronize(pool);  // the copies run concurrently on the members' own streams until here
 }
 
+int tfhe_pool_replicate_key(tfhe_pool* pool) {
+  if (!pool) return TFHE_ERR_INVALID_ARGUMENT;
+  if (!pool->members[0]->have_key) return pool_fail(pool, TFHE_ERR_NO_KEY, "member 0 holds no key to replicate");
+  return replicate_from_member0(pool);
+}
+
+// bootstrapping_key_gen (bootstrapping.rs:23-56) for the whole pool: generated on member 0's device, and with `load`
+// installed on EVERY member (a key installed on member 0 alone would leave the other members without a key -- or, worse,
+// bootstrapping their slices under the key loaded before)
+static int pool_key_gen(tfhe_pool* pool, const uint32_t* lwe_sk, const uint32_t* glwe_sk, uint32_t* bsk, uint32_t* ksk,
+                        int load, bool bmmp) {
+  if (!pool) return TFHE_ERR_INVALID_ARGUMENT;
+  int st = (bmmp ? tfhe_bootstrapping_key_gen_bmmp : tfhe_bootstrapping_key_gen)(pool->members[0], lwe_sk, glwe_sk, bsk, ksk, load);
+  if (st) return member_fail(pool, 0, st);
+  return load ? replicate_from_member0(pool) : TFHE_OK;
+}
+
+int tfhe_pool_bootstrapping_key_gen(tfhe_pool* pool, const uint32_t* lwe_sk, const uint32_t* glwe_sk, uint32_t* bsk,
+                                    uint32_t* ksk, int load) {
+  return pool_key_gen(pool, lwe_sk, glwe_sk, bsk, ksk, load, false);
+}
+
+int tfhe_pool_bootstrapping_key_gen_bmmp(tfhe_pool* pool, const uint32_t* lwe_sk, const uint32_t* glwe_sk,
+                                         uint32_t* bsk_bmmp, uint32_t* ksk, int load) {
+  return pool_key_gen(pool, lwe_sk, glwe_sk, bsk_bmmp, ksk, load, true);
+}
+
 int tfhe_pool_load_bootstrapping_key(tfhe_pool* pool, const uint32_t* bsk, const uint32_t* ksk) {
   if (!pool) return TFHE_ERR_INVALID_ARGUMENT;
   int st = tfhe_load_bootstrapping_key(pool->members[0], bsk, ksk);
@@ -207,6 +245,17 @@ int tfhe_pool_bootstrap_shards_device(tfhe_pool* pool, const uint32_t* const* lw
                                       const uint32_t* const* tv, const size_t* tv_counts, uint32_t* const* lwe_out) {
   if (!pool) return TFHE_ERR_INVALID_ARGUMENT;
   if (!lwe_in || !counts || !tv || !tv_counts || !lwe_out) return pool_fail(pool, TFHE_ERR_INVALID_ARGUMENT, "null pointer");
+  // validate every member's arguments BEFORE anything is enqueued: a call either launches on all members with work
+  // or on none (a failure half way would leave a partially launched step the caller cannot tell from a failed one)
+  for (size_t i = 0; i < pool->members.size(); ++i) {
+    if (counts[i] == 0) continue;
+    tfhe_context* m = pool->members[i];
+    if (!m->have_key) return pool_fail(pool, TFHE_ERR_NO_KEY, "member " + std::to_string(i) + " holds no key");
+    if (!lwe_in[i] || !tv[i] || !lwe_out[i]) return pool_fail(pool, TFHE_ERR_INVALID_ARGUMENT, "member " + std::to_string(i) + ": null pointer");
+    if (tv_counts[i] != 1 && tv_counts[i] != counts[i])
+      return pool_fail(pool, TFHE_ERR_INVALID_ARGUMENT, "member " + std::to_string(i) + ": tv_count must be 1 or the shard's count");
+    if (counts[i] > 0x7FFFFFFFull) return pool_fail(pool, TFHE_ERR_INVALID_ARGUMENT, "member " + std::to_string(i) + ": shard exceeds 2^31 - 1");
+  }
   // enqueue only: one launch sequence per member on its own stream, nothing waits here
   for (size_t i = 0; i < pool->members.size(); ++i) {
     if (counts[i] == 0) continue;

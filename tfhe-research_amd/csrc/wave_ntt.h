@@ -375,11 +375,7 @@ TFHE_HD void ntt_transpose_multi(const Ctx (&c)[NS], typename F::elem (&x)[NS][N
   constexpr bool READS_CROSS = G > 1 && LO_TO > 6;
   static_assert(!(WRITES_CROSS && READS_CROSS), "one of the two windows is a low one");
   const int tid = c[0].tid();
-  // (TFHE_PROBE_NO_TRANSPOSE: timing probe, WRONG BITS -- the register windows are not exchanged: what is left is the
-  // kernel without the LDS round trips of its transposes.  Dev builds only.)
-#ifndef TFHE_PROBE_NO_TRANSPOSE
-#define TFHE_PROBE_NO_TRANSPOSE 0
-#endif
+  // (TFHE_PROBE_NO_TRANSPOSE: dev_switches.h -- a WRONG-BITS timing probe, TFHE_DEV_BUILD only)
   if (TFHE_PROBE_NO_TRANSPOSE) return;
   if (WRITES_CROSS && !SKIP_LEAD) c[0].poly_sync();
 #pragma unroll
