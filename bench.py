@@ -384,7 +384,9 @@ def bench_batch_sweep(args, pkg, dev, local_rank, backend):
             ctx.set_decomposer_alignment(True)   # cfg2: the data-dependent timing (the literal decomposer multiplies zeros)
         ctx.reserve(max(sizes))
         ctx.set_timing(True)
-        for b in sizes:
+        shapes = {"auto": pkg.SHAPE_AUTO, "wide": pkg.SHAPE_WIDE, "team": pkg.SHAPE_TEAM}
+        for shape_name, b in [(sn, b) for sn in args.sweep_shapes.split(",") for b in sizes]:
+            ctx.set_kernel_shape(shapes[shape_name])
             lwe = lwe_all[:b]
             out = torch.empty_like(lwe)
             reps = max(10, min(200, 4096 // b))
@@ -403,7 +405,7 @@ def bench_batch_sweep(args, pkg, dev, local_rank, backend):
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             br, ksm = ctx.kernel_ms_ago(0)
-            rows.append({"workload": wl, "batch": b, "latency_ms": float(np.median(lat)) * 1e3,
+            rows.append({"workload": wl, "shape": shape_name, "batch": b, "latency_ms": float(np.median(lat)) * 1e3,
                          "latency_ms_min": float(np.min(lat)) * 1e3, "pbs_per_s": b * reps / dt,
                          "blind_rotate_ms": br, "key_switch_ms": ksm, "reps": reps, "plan": ctx.blind_rotate_plan(b),
                          "backend": ctx.backend})
@@ -511,6 +513,8 @@ def main():
                          "ONE ciphertext per bootstrap()); prints one JSON line with a row per (workload, batch)")
     ap.add_argument("--sweep-batches", default="1,8,64,256,1024,4096")
     ap.add_argument("--sweep-workloads", default="cfg2,cfg3")
+    ap.add_argument("--sweep-shapes", default="auto",
+                    help="kernel shapes to sweep (tfhe_context_set_kernel_shape): auto, wide, team; e.g. team,wide for the A/B")
     ap.add_argument("--gate", default="", choices=["", "nand", "and", "or", "xor"],
                     help="step = one homomorphic gate over the batch (boolean.rs: bootstrap(2*ct1 + ct0)) instead of a plain PBS")
     args = ap.parse_args()

@@ -308,6 +308,20 @@ int tfhe_bootstrapping_key_gen_bmmp_device(tfhe_context *ctx, const uint32_t *lw
  * keys serve both orders. */
 int tfhe_context_set_bootstrap_order(tfhe_context *ctx, int ks_first);
 
+/* ---- kernel shape of the blind rotation -----------------------------------------------------------
+ * The reference's call shape is ONE ciphertext per bootstrap() (bootstrapping.rs:58-65) and one pair per gate
+ * (boolean.rs:9-37).  Two kernels compute the same bits:
+ *   TFHE_SHAPE_TEAM  k+1 wave groups per sample (two samples per team where they fit): the throughput shape, the only
+ *                    one for the prime-field backends and N = 2048;
+ *   TFHE_SHAPE_WIDE  2 (k+1) waves per sample, split by digit level and key part: about half the time per CMUX of one
+ *                    sample on an idle chip -- the latency shape (FP64_FFT backend, N <= 1024; elsewhere the team runs);
+ *   TFHE_SHAPE_AUTO  (default) the launcher picks by batch: wide while the batch leaves most CUs idle.
+ * Affects every entry point that rotates (bootstrap, blind_rotate, gates). */
+#define TFHE_SHAPE_AUTO 0
+#define TFHE_SHAPE_WIDE 1
+#define TFHE_SHAPE_TEAM 2
+int tfhe_context_set_kernel_shape(tfhe_context *ctx, int shape);
+
 /* ---- decomposer alignment ------------------------------------------------------
  * 0 (default): the reference's literal decomposer -- limbs counted from bit 0 (decomposer.rs:48-70),
  * gadget factors beta^{floor(32/log_base)-(level+1)} (ggsw.rs:98, key_switching.rs:38), bit-exact

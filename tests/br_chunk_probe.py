@@ -21,6 +21,7 @@ for k, logn, n, pbs, log_p in ((2, 9, 4, (4, 6), 2), (2, 11, 2, (8, 4), 4), (1, 
     lwe, bsk, ksk, tv = orc.synthetic_inputs(p, 8, cfg_index=30 + logn)
     tvs = np.stack([np.roll(tv, 7 * b) for b in range(8)])
     with m.Context(to_pkg_params(p)) as ctx:
+        ctx.set_kernel_shape(m.SHAPE_TEAM)   # the launch plan under test is the team kernel's (a batch of 8 would go wide)
         ctx.load_bootstrapping_key(bsk, ksk)
         out = ctx.bootstrap(lwe, tvs)
         acc = ctx.blind_rotate(lwe, tvs)

@@ -267,21 +267,14 @@ template <class Elem>
 struct HostWideWave {
   int lane_, wave_;
   HostWideTeam<Elem>* t_;
-  int row_;
   int tid() const { return lane_; }
   int group() const { return wave_ >> 1; }
   int half() const { return wave_ & 1; }
-  int wave_index() const { return wave_; }
-  HostWideWave with_row(int r) const {
-    HostWideWave w = *this;
-    w.row_ = r;
-    return w;
-  }
-  const Elem* row_buffer(int r) const { return t_->buffers.data() + (size_t)r * t_->ns; }
+  Elem* row_buffer(int r) const { return t_->buffers.data() + (size_t)r * t_->ns; }
   void wave_sync() const { pthread_barrier_wait(&t_->wave_bars[wave_]); }
   void poly_sync() const { wave_sync(); }
   void team_sync() const { pthread_barrier_wait(&t_->team_bar); }
-  Elem* scratch() const { return t_->buffers.data() + (size_t)row_ * t_->ns; }
+  Elem* scratch() const { return t_->buffers.data() + (size_t)(t_->rows + wave_) * t_->ns; }  // my own transpose buffer
   u32* acc(int = 0) const { return t_->acc.data() + (size_t)group() * t_->n; }
   const Elem* twiddles() const { return t_->tw.data(); }
   const Elem* twiddles_uniform() const { return t_->tw_natural.data(); }
@@ -301,8 +294,8 @@ void blind_rotate_wide(const PbsParams& P, size_t batch, const u32* lwe, const u
   team.n = N;
   team.ns = 1 << LT;
   team.waves = 2 * (K + 1);
-  team.rows = (K + 1) * (P.levels > 2 ? (int)P.levels : 2);
-  team.buffers.resize((size_t)team.rows * team.ns);
+  team.rows = (K + 1) * (int)P.levels;
+  team.buffers.resize((size_t)(team.rows + team.waves) * team.ns);
   team.acc.resize((size_t)(K + 1) * N);
   team.tw_natural.resize(ntt_twiddle_words(team.ns));
   F::fill_twiddles(LT, team.tw_natural.data());
@@ -342,7 +335,7 @@ void blind_rotate_wide(const PbsParams& P, size_t batch, const u32* lwe, const u
   for (int wv = 0; wv < team.waves; ++wv)
     for (int l = 0; l < kWave; ++l)
       th.emplace_back([&, wv, l] {
-        HostWideWave<elem> ctx{l, wv, &team, wv};
+        HostWideWave<elem> ctx{l, wv, &team};
         body(ctx);
       });
   for (auto& t : th) t.join();

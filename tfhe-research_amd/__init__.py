@@ -31,6 +31,7 @@ STATUS_NAMES = {
 FILE_BSK, FILE_KSK, FILE_LWE, FILE_GLWE, FILE_GGSW, FILE_WORDS = 1, 2, 3, 4, 5, 6
 DECOMPOSER_PBS, DECOMPOSER_KS = 0, 1
 BACKEND_AUTO, BACKEND_GOLDILOCKS, BACKEND_FP64, BACKEND_GOLDILOCKS_SPLIT, BACKEND_FP64_P49, BACKEND_FP64_FFT = 0, 1, 2, 3, 4, 5
+SHAPE_AUTO, SHAPE_WIDE, SHAPE_TEAM = 0, 1, 2   # tfhe_context_set_kernel_shape
 
 # truth[(lhs << 1) | rhs]
 GATE_AND = (0, 0, 0, 1)
@@ -349,6 +350,11 @@ class Context:
         """False: the reference's literal decomposer (bit-exact with the crate).  True: limbs and
         gadget factors counted down from bit 32, so bases with log_base not dividing 32 decrypt."""
         self._check(lib().tfhe_context_set_decomposer_alignment(self._h, C.c_int(int(aligned))))
+
+    def set_kernel_shape(self, shape: int):
+        """SHAPE_AUTO (default: by batch size), SHAPE_WIDE (2 (k+1) waves per sample: the latency shape, fp64-fft up to
+        N = 1024) or SHAPE_TEAM (the throughput shape) for every blind rotation of this context; same bits either way"""
+        self._check(lib().tfhe_context_set_kernel_shape(self._h, C.c_int(int(shape))))
 
     def set_bootstrap_order(self, ks_first: bool):
         """False: PBS then key switch (bootstrapping.rs:58-120), ciphertexts of n+1 words.  True:

@@ -140,7 +140,7 @@ hipError_t enqueue_blind_rotate(tfhe_context* ctx, const u32* lwe_in, size_t bat
   // accumulators between the launches of a segmented rotation: the caller's output, or the workspace (sized by reserve)
   u32* state = glwe_out ? glwe_out : (batch <= ctx->ws_batch ? ctx->d_glwe_c : nullptr);
   return launch::blind_rotate(ctx->stream, ctx->field, ctx->pbs, ctx->d_tw, lwe_in, batch, tv, tv_count == 1 ? 0 : ctx->N,
-                              ctx->d_bsk, glwe_out, lwe_extracted, state, &ctx->side);
+                              ctx->d_bsk, glwe_out, lwe_extracted, state, &ctx->side, ctx->shape);
 }
 
 // d_lwe_big: [batch][k*N+1] scratch of the reference order (unused when the key switch comes first)
@@ -434,6 +434,12 @@ int tfhe_context_create_with_backend(const tfhe_params* params, int device, int 
   if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->d_queue), 2 * sizeof(unsigned long long))) != hipSuccess ||
       (e = hipMemset(ctx->d_queue, 0, 2 * sizeof(unsigned long long))) != hipSuccess)
     return bail(e, "work queue");
+  // TFHE_KERNEL_SHAPE=wide|team: the starting value of tfhe_context_set_kernel_shape (test sweeps: the whole suite under
+  // one shape); unset or anything else: TFHE_SHAPE_AUTO
+  if (const char* shape = std::getenv("TFHE_KERNEL_SHAPE")) {
+    if (std::strcmp(shape, "wide") == 0) ctx->shape = TFHE_SHAPE_WIDE;
+    else if (std::strcmp(shape, "team") == 0) ctx->shape = TFHE_SHAPE_TEAM;
+  }
   *out = ctx;
   return TFHE_OK;
 }
@@ -511,6 +517,14 @@ int tfhe_context_set_decomposer_alignment(tfhe_context* ctx, int aligned) {
   ctx->aligned = aligned != 0;
   ctx->pbs.first_shift = gadget_top(ctx, ctx->pbs.log_base) - ctx->pbs.log_base * ctx->pbs.levels;
   ctx->ks.first_shift = gadget_top(ctx, ctx->ks.log_base) - ctx->ks.log_base * ctx->ks.levels;
+  return TFHE_OK;
+}
+
+int tfhe_context_set_kernel_shape(tfhe_context* ctx, int shape) {
+  if (!ctx) return TFHE_ERR_INVALID_ARGUMENT;
+  if (shape != TFHE_SHAPE_AUTO && shape != TFHE_SHAPE_WIDE && shape != TFHE_SHAPE_TEAM)
+    return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "kernel shape: TFHE_SHAPE_AUTO, TFHE_SHAPE_WIDE or TFHE_SHAPE_TEAM");
+  ctx->shape = shape;
   return TFHE_OK;
 }
 
@@ -593,7 +607,7 @@ int tfhe_debug_blind_rotate_plan(tfhe_context* ctx, size_t batch, size_t* sample
   launch::BlindRotatePlanInfo plan{};
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   // the plan of tfhe_bootstrap_batch[_device], which reserve the workspace the accumulators are parked in
-  HIP_TRY(ctx, launch::blind_rotate_plan(ctx->field, ctx->pbs, batch, !ctx->bmmp, ctx->side.stream != nullptr, &plan));
+  HIP_TRY(ctx, launch::blind_rotate_plan(ctx->field, ctx->pbs, batch, !ctx->bmmp, ctx->side.stream != nullptr, &plan, ctx->shape));
   *samples_per_group = plan.chunk;
   *segments = ctx->bmmp ? 1u : plan.segments;
   *streams = ctx->bmmp ? 1u : (unsigned)plan.streams;
@@ -606,7 +620,7 @@ int tfhe_debug_blind_rotate_shape(tfhe_context* ctx, size_t batch, unsigned* wav
   if (st) return st;
   if (!waves_per_sample || !samples_per_team) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer");
   launch::BlindRotatePlanInfo plan{};
-  HIP_TRY(ctx, launch::blind_rotate_plan(ctx->field, ctx->pbs, batch, !ctx->bmmp, ctx->side.stream != nullptr, &plan));
+  HIP_TRY(ctx, launch::blind_rotate_plan(ctx->field, ctx->pbs, batch, !ctx->bmmp, ctx->side.stream != nullptr, &plan, ctx->shape));
   *waves_per_sample = (unsigned)plan.waves_per_sample;
   *samples_per_team = (unsigned)plan.samples_per_team;
   return TFHE_OK;

@@ -33,6 +33,7 @@ struct tfhe_context {
   size_t bsk_ggsws = 0;       // GGSWs d_bsk was allocated for
   bool aligned = false;       // decomposer alignment (tfhe_context_set_decomposer_alignment)
   bool ks_first = false;      // bootstrap order (tfhe_context_set_bootstrap_order)
+  int shape = 0;              // kernel shape of the blind rotation (tfhe_context_set_kernel_shape): launch::kShape*
 
   // workspace (grown on demand by host-pointer calls or tfhe_context_reserve)
   size_t ws_batch = 0;

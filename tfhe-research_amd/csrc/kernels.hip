@@ -345,11 +345,11 @@ blind_rotate_kernel(PbsParams P, const typename F::elem* __restrict__ tw,
 // The latency shape (pbs_wave.h::blind_rotate_team_wide): 2 (K+1) waves per sample -- wave (c, q) transforms half of
 // polynomial c's digit levels, accumulates key part q of column c over all rows and inverse-transforms that one
 // accumulator.  The complex transform up to N = 1024.  Picked by the launcher for batches that leave most CUs idle.
-// LDS: [ twiddles ][ RB row buffers of N x 8 B ][ K+1 accumulator polynomials of N x 4 B ], RB = max((K+1) l, 2 (K+1))
+// LDS: [ twiddles ][ (K+1) l row buffers of N x 8 B ][ 2 (K+1) transpose buffers, one per wave ][ K+1 accumulator polynomials of N x 4 B ]
 template <class Elem>
 struct WideWave {
   unsigned char* rows_;  // row buffer 0
-  Elem* scratch_;        // the row buffer this copy transposes in
+  Elem* scratch_;        // my own transpose buffer
   u32* acc_;             // my polynomial's accumulator
   const Elem* tw_;
   const Elem* twg_;
@@ -358,13 +358,7 @@ struct WideWave {
   __device__ __forceinline__ int tid() const { return (int)(threadIdx.x & 63u); }
   __device__ __forceinline__ int group() const { return wave_ >> 1; }
   __device__ __forceinline__ int half() const { return wave_ & 1; }
-  __device__ __forceinline__ int wave_index() const { return wave_; }
-  __device__ __forceinline__ WideWave with_row(int r) const {
-    WideWave w = *this;
-    w.scratch_ = reinterpret_cast<Elem*>(rows_ + (size_t)r * row_bytes_);
-    return w;
-  }
-  __device__ __forceinline__ const Elem* row_buffer(int r) const { return reinterpret_cast<const Elem*>(rows_ + (size_t)r * row_bytes_); }
+  __device__ __forceinline__ Elem* row_buffer(int r) const { return reinterpret_cast<Elem*>(rows_ + (size_t)r * row_bytes_); }
   __device__ __forceinline__ void wave_sync() const {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -390,12 +384,17 @@ struct WideCfg {
   static constexpr int kThreads = kWaves * 64;
   static constexpr size_t kTwBytes = (size_t)staged_twiddle_words<F, LOGN>() * sizeof(typename F::elem);
   static constexpr unsigned kRowBytes = (unsigned)N * 8u;
-  static __host__ __device__ size_t row_buffers(u32 levels) { return (size_t)(K + 1) * (levels > 2u ? levels : 2u); }
+  static __host__ __device__ size_t row_buffers(u32 levels) { return (size_t)(K + 1) * levels + kWaves; }  // rows, then one per wave
   static __host__ __device__ size_t lds(u32 levels) { return kTwBytes + row_buffers(levels) * kRowBytes + (size_t)(K + 1) * N * 4; }
 };
 
+// (waves per SIMD the register allocation aims at: with 1 the compiler takes 260 registers at N = 1024, k = 1 and spills 67
+// at k = 2, whose six waves put two on two of the SIMDs anyway)
+#ifndef TFHE_WIDE_MIN_WAVES
+#define TFHE_WIDE_MIN_WAVES 2
+#endif
 template <class F, int LOGN, int K>
-__global__ void __launch_bounds__((WideCfg<F, LOGN, K>::kThreads), 1)
+__global__ void __launch_bounds__((WideCfg<F, LOGN, K>::kThreads), TFHE_WIDE_MIN_WAVES)
 blind_rotate_wide_kernel(PbsParams P, const typename F::elem* __restrict__ tw, const u32* __restrict__ lwe_in, size_t batch,
                          const u32* __restrict__ tv, size_t tv_stride, const typename F::elem* __restrict__ bsk,
                          u32* glwe_out, u32* __restrict__ lwe_extracted, u32 i_begin, u32 i_end, u32* glwe_state) {
@@ -410,7 +409,7 @@ blind_rotate_wide_kernel(PbsParams P, const typename F::elem* __restrict__ tw, c
   w.wave_ = (int)(threadIdx.x >> 6);
   w.rows_ = g_smem + C::kTwBytes;
   w.row_bytes_ = C::kRowBytes;
-  w.scratch_ = reinterpret_cast<elem*>(w.rows_ + (size_t)w.wave_ * C::kRowBytes);
+  w.scratch_ = reinterpret_cast<elem*>(w.rows_ + ((size_t)(K + 1) * P.levels + w.wave_) * C::kRowBytes);
   w.acc_ = reinterpret_cast<u32*>(w.rows_ + C::row_buffers(P.levels) * C::kRowBytes) + (size_t)w.group() * N;
   w.tw_ = twl;
   w.twg_ = tw;
@@ -1009,12 +1008,13 @@ constexpr bool wide_shape_ok() {
   return F::kLogShrink == 1 && F::kParts == 2 && LOGN <= 10 && field_shape_ok<F, LOGN>();
 }
 template <class F, int LOGN, int K>
-size_t wide_max_batch(const PbsParams& P) {
+size_t wide_max_batch(const PbsParams& P, int shape) {
   if constexpr (!wide_shape_ok<F, LOGN, K>()) {
     return 0;
   } else {
     using W = WideCfg<F, LOGN, K>;
-    if (W::lds(P.levels) > (size_t)160 * 1024) return 0;
+    if (W::lds(P.levels) > (size_t)160 * 1024 || shape == launch::kShapeTeam) return 0;
+    if (shape == launch::kShapeWide) return ~(size_t)0;
     static const long env_wide = std::getenv("TFHE_BR_WIDE") ? std::atol(std::getenv("TFHE_BR_WIDE")) : -1;
     if (env_wide >= 0) return (size_t)env_wide;
     int cus = 0;
@@ -1045,7 +1045,7 @@ hipError_t launch_blind_rotate_wide(hipStream_t s, const PbsParams& P, const typ
 }
 
 template <class F, int LOGN, int K>
-hipError_t plan_blind_rotate(const PbsParams& P, size_t batch, bool can_park, bool have_side, launch::BlindRotatePlanInfo* out) {
+hipError_t plan_blind_rotate(const PbsParams& P, size_t batch, bool can_park, bool have_side, launch::BlindRotatePlanInfo* out, int shape) {
   if constexpr (!field_shape_ok<F, LOGN>()) {
     return hipErrorInvalidValue;
   } else {
@@ -1063,7 +1063,7 @@ hipError_t plan_blind_rotate(const PbsParams& P, size_t batch, bool can_park, bo
     out->resident_samples = (size_t)capacity * C::S;
     out->samples_per_team = C::S;
     out->waves_per_sample = C::kWaves;
-    if (batch > 0 && batch <= wide_max_batch<F, LOGN, K>(P)) {  // the wide team: one launch over the whole key
+    if (batch > 0 && batch <= wide_max_batch<F, LOGN, K>(P, shape)) {  // the wide team: one launch over the whole key
       out->chunk = batch;
       out->segments = 1;
       out->streams = 1;
@@ -1077,7 +1077,7 @@ hipError_t plan_blind_rotate(const PbsParams& P, size_t batch, bool can_park, bo
 template <class F, int LOGN, int K>
 hipError_t launch_blind_rotate(hipStream_t s, const PbsParams& P, const void* tw_v, const u32* lwe_in,
                                size_t batch, const u32* tv, size_t tv_stride, const void* bsk_v,
-                               u32* glwe_out, u32* lwe_extracted, u32* state, const launch::SideStream* side) {
+                               u32* glwe_out, u32* lwe_extracted, u32* state, const launch::SideStream* side, int shape) {
   if constexpr (!field_shape_ok<F, LOGN>()) {
     return hipErrorInvalidValue;  // the context never picks such a field (capi.cpp)
   } else {
@@ -1085,7 +1085,7 @@ hipError_t launch_blind_rotate(hipStream_t s, const PbsParams& P, const void* tw
     auto tw = static_cast<const typename F::elem*>(tw_v);
     auto bsk = static_cast<const typename F::elem*>(bsk_v);
     if constexpr (wide_shape_ok<F, LOGN, K>()) {
-      if (batch <= wide_max_batch<F, LOGN, K>(P))
+      if (batch <= wide_max_batch<F, LOGN, K>(P, shape))
         return launch_blind_rotate_wide<F, LOGN, K>(s, P, tw, lwe_in, batch, tv, tv_stride, bsk, glwe_out, lwe_extracted);
     }
     auto kern = blind_rotate_kernel<F, LOGN, K>;
@@ -1366,15 +1366,15 @@ hipError_t bsk_prepare(hipStream_t s, int field, u32 log_n, const void* tw, cons
 
 hipError_t blind_rotate(hipStream_t s, int field, const PbsParams& P, const void* tw,
                         const u32* lwe_in, size_t batch, const u32* tv, size_t tv_stride,
-                        const void* bsk, u32* glwe_out, u32* lwe_extracted, u32* state, const SideStream* side) {
+                        const void* bsk, u32* glwe_out, u32* lwe_extracted, u32* state, const SideStream* side, int shape) {
   TFHE_DISPATCH_FIELD(field, TFHE_DISPATCH_LOGN_K(P.log_n, P.k,
                       (launch_blind_rotate<FF, LL, KK>(s, P, tw, lwe_in, batch, tv, tv_stride, bsk,
-                                                       glwe_out, lwe_extracted, state, side))));
+                                                       glwe_out, lwe_extracted, state, side, shape))));
 }
 
 hipError_t blind_rotate_plan(int field, const PbsParams& P, size_t batch, bool can_park, bool have_side,
-                             BlindRotatePlanInfo* out) {
-  TFHE_DISPATCH_FIELD(field, TFHE_DISPATCH_LOGN_K(P.log_n, P.k, (plan_blind_rotate<FF, LL, KK>(P, batch, can_park, have_side, out))));
+                             BlindRotatePlanInfo* out, int shape) {
+  TFHE_DISPATCH_FIELD(field, TFHE_DISPATCH_LOGN_K(P.log_n, P.k, (plan_blind_rotate<FF, LL, KK>(P, batch, can_park, have_side, out, shape))));
 }
 
 hipError_t blind_rotate_bmmp(hipStream_t s, int field, const PbsParams& P, const void* tw,

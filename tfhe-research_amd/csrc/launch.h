@@ -35,6 +35,11 @@ struct SideStream {
   hipEvent_t fork, join;
 };
 
+// Kernel shape of a blind rotation (tfhe_context_set_kernel_shape): the launcher's own choice by batch size, the wide
+// team (2 (k+1) waves per sample: the latency shape, complex transform up to N = 1024) wherever it is offered, or
+// always the throughput team
+constexpr int kShapeAuto = 0, kShapeWide = 1, kShapeTeam = 2;
+
 // Blind rotation of `batch` samples.  Optional outputs: glwe_out [batch][k+1][N] and/or
 // lwe_extracted [batch][k*N+1] (sample extract at index 0 fused in).
 // `state`: [batch][k+1][N] words of scratch that hold the accumulators between the launches of a segmented rotation
@@ -43,7 +48,7 @@ struct SideStream {
 hipError_t blind_rotate(hipStream_t s, int field, const PbsParams& P, const void* tw,
                         const u32* lwe_in, size_t batch, const u32* tv, size_t tv_stride,
                         const void* bsk, u32* glwe_out, u32* lwe_extracted, u32* state = nullptr,
-                        const SideStream* side = nullptr);
+                        const SideStream* side = nullptr, int shape = kShapeAuto);
 
 // How blind_rotate would send out a batch (kernels.hip::blind_rotate_plan), for bench lines and tests
 struct BlindRotatePlanInfo {
@@ -55,7 +60,7 @@ struct BlindRotatePlanInfo {
   int waves_per_sample;     // K+1 groups of G waves (shared by samples_per_team samples), or 2 (K+1) for the wide team
 };
 hipError_t blind_rotate_plan(int field, const PbsParams& P, size_t batch, bool can_park, bool have_side,
-                             BlindRotatePlanInfo* out);
+                             BlindRotatePlanInfo* out, int shape = kShapeAuto);
 
 // The unrolled blind rotation of notes/BMMP Bootstrapping.md (two key bits per step): bsk holds
 // n/2 * 3 prepared GGSWs (pbs_wave.h::blind_rotate_bmmp_team); n even, shape_supported_bmmp only.

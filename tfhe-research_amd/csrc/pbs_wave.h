@@ -628,19 +628,18 @@ TFHE_HD void blind_rotate_team(const Ctx& c, const PbsParams& P, const u32* lwe 
 //     chain from the lowest limb, but forward-transforms only ITS levels -- the lower ceil(l/2) limbs for q = 0,
 //     the upper ones for q = 1 -- each in the LDS buffer of its digit row (row = c l + level), where the
 //     spectrum then stays published;
-//   - barrier A: all (K+1) l digit spectra are visible;
+//   - barrier A: all (K+1) l digit spectra are visible (and every wave has read the accumulator polynomials);
 //   - accumulates key part q of column c over ALL rows (half the tiles of a one-wave-per-polynomial team);
-//   - barrier B: nobody reads a spectrum any more, the buffers are free;
-//   - inverse-transforms its one accumulator (in buffer number 2c + q) and adds lift(part q) << 16 q to the
+//   - inverse-transforms its one accumulator (in its own transpose buffer) and adds lift(part q) << 16 q to the
 //     accumulator polynomial with ds_add_u32 -- wrapping addition commutes, so the two halves of a column need
-//     no order: acc_c += t_lo + 2^16 t_hi mod 2^32 exactly as FftField::finish forms it.
+//     no order: acc_c += t_lo + 2^16 t_hi mod 2^32 exactly as FftField::finish forms it;
+//   - barrier B (the caller's, after the product): the accumulators are complete and the row buffers free.
 // Per wave and CMUX at N = 1024, k = 1, l = 3: 2 (or 1) forward transforms, 6 tiles, 1 inverse transform instead
 // of 3, 12 and 2.  The same exact integer sums in another order: same bits (field_fft.h: the rounding bound does
-// not depend on the order of the rows).  Needs max((K+1) l, 2 (K+1)) buffers of N x 8 bytes in LDS: offered up to
-// N = 1024.  Three team barriers per CMUX.
+// not depend on the order of the rows).  Needs (K+1) l row buffers and 2 (K+1) transpose buffers of N x 8 bytes in
+// LDS: offered up to N = 1024.  TWO team barriers per CMUX, whatever the level count.
 //
-// Ctx additionally provides: half() (q), wave_index() (2c + q), with_row(r): a copy whose scratch() is row buffer r,
-// row_buffer(r): that buffer for reading.
+// Ctx additionally provides: half() (q), row_buffer(r): the buffer of digit row r; scratch() is the wave's own buffer.
 // ---------------------------------------------------------------------------------------------
 template <class F, int LOGN, int K, class Ctx, class Src, class Out>
 TFHE_HD void external_product_team_wide(const Ctx& c, const PbsParams& P, const typename F::elem* ggsw, Src src, Out out) {
@@ -697,12 +696,12 @@ TFHE_HD void external_product_team_wide(const Ctx& c, const PbsParams& P, const 
     }
     if (t < t_begin) continue;  // (wave-uniform) my twin's limb: only the carries were needed
     const u32 row = (u32)me * P.levels + (P.levels - 1u - t);
-    const Ctx cr = c.with_row((int)row);
-    // (nobody has touched the row buffers since barrier C of the previous product)
-    ntt_forward<F, LT, 1, true, true>(cr, work, ftop);
-    elem* mine = cr.scratch();
+    // transposes in my own buffer (fixed addresses: the swizzled offsets stay loop invariants), the spectrum then goes
+    // to its row's buffer, which nobody has read since barrier B of the previous product
+    ntt_forward<F, LT, 1, true, true>(c, work, ftop);
+    elem* published = c.row_buffer((int)row);
 #pragma unroll
-    for (int r = 0; r < E; ++r) mine[exchange_slot<LT, 1>(lane, r)] = work[r];
+    for (int r = 0; r < E; ++r) published[exchange_slot<LT, 1>(lane, r)] = work[r];
   }
   TopConsts<F, LT, 1, false> itop;  // arrives under the multiply-accumulate
   itop.issue(c.twiddles_uniform());
@@ -732,13 +731,13 @@ TFHE_HD void external_product_team_wide(const Ctx& c, const PbsParams& P, const 
       for (int r = 0; r < CH; ++r) accum[r0 + r] = F::mul_add(d[r], kbuf[cur][r], accum[r0 + r]);
     });
   }
-  c.team_sync();  // B: the spectra are done with; any buffer may be written again
+  // (no barrier here: the inverse transform works in my own buffer and the accumulator polynomial is only read before
+  // barrier A; the row buffers are written again after barrier C)
 
 #pragma unroll
   for (int r = 0; r < E; ++r) accum[r] = F::before_inverse(accum[r]);
   itop.ready();
-  const Ctx ci = c.with_row(c.wave_index());
-  ntt_inverse<F, LT, 1>(ci, accum, itop);
+  ntt_inverse<F, LT, 1>(c, accum, itop);
 #pragma unroll
   for (int r = 0; r < E; ++r) {
     out(q, r * T + lane, F::to_u32(accum[r].re));
@@ -785,10 +784,10 @@ TFHE_HD void blind_rotate_team_wide(const Ctx& c, const PbsParams& P, const u32*
   for (u32 i = i_begin; i < i_end; ++i) {
     const u32 a_tilde = c.uniform(switch_modulus_2n(lwe[i], LOGN));
     auto src = [&](int j) -> u32 { return monomial_coeff<LOGN>(acc, j, a_tilde) - acc[j]; };
-    // every rotated read of acc happens before barrier A, every update after barrier B: in place is safe
+    // every rotated read of acc happens before barrier A, every update after it: in place is safe
     auto out = [&](int half, int j, u32 value) { c.lds_add(acc + j, value << (16 * half)); };
     external_product_team_wide<F, LOGN, K>(c, P, bsk + (size_t)i * ggsw_words, src, out);
-    c.team_sync();  // C: both halves of every column have added their part
+    c.team_sync();  // B: both halves of every column have added their part; all reads of the spectra are over
   }
 }
 

@@ -29,8 +29,11 @@ print(f"# {bits}-bit ripple-carry adder: {pbs_gates} gates (one PBS each), depth
 print("# instances  eager_ms  graph_ms  gates_per_s(graph)")
 bsk = torch.randint(-2**31, 2**31 - 1, p.bsk_shape(), dtype=torch.int32, device=dev)
 ksk = torch.randint(-2**31, 2**31 - 1, p.ksk_shape(), dtype=torch.int32, device=dev)
+shape = {"auto": m.SHAPE_AUTO, "wide": m.SHAPE_WIDE, "team": m.SHAPE_TEAM}[os.environ.get("GATE_GRAPH_SHAPE", "auto")]
+print(f"# kernel shape: {os.environ.get('GATE_GRAPH_SHAPE', 'auto')} (tfhe_context_set_kernel_shape)")
 for inst in (64, 1024, 4096):
     with m.Context(to_pkg_params(p)) as ctx:
+        ctx.set_kernel_shape(shape)
         ctx.load_bootstrapping_key(bsk, ksk)
         x = torch.randint(-2**31, 2**31 - 1, (inst, circuit.n_inputs, p.n + 1), dtype=torch.int32, device=dev)
         gc = gates.GraphedCircuit(ctx, circuit, inst, dev)
