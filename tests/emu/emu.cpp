@@ -284,7 +284,9 @@ struct HostWideWave {
   void compiler_fence() const {}
 };
 
-template <class F, int LOGN, int K>
+int g_wide_key_ring = 1;  // 1: the key-ring instantiation where one exists for the level count (2, 3, 4, 6); 0: the generic kernel
+
+template <class F, int LOGN, int K, int LEVELS = 0>
 void blind_rotate_wide(const PbsParams& P, size_t batch, const u32* lwe, const u32* tv, size_t tv_stride,
                        const typename F::elem* bsk, u32* out_glwe, u32* out_lwe) {
   typedef typename F::elem elem;
@@ -312,7 +314,8 @@ void blind_rotate_wide(const PbsParams& P, size_t batch, const u32* lwe, const u
       const u32 per = (P.n + g_segments - 1) / g_segments;
       for (u32 i0 = 0; i0 < P.n; i0 += per) {
         const u32 i1 = i0 + per < P.n ? i0 + per : P.n;
-        blind_rotate_team_wide<F, LOGN, K>(w, P, lwe + b * (P.n + 1), tv + b * tv_stride, bsk, i0, i1, state.data());
+        blind_rotate_team_wide<F, LOGN, K, LEVELS, wide_ring_rows<LOGN, K, LEVELS>()>(w, P, lwe + b * (P.n + 1), tv + b * tv_stride, bsk, i0, i1,
+                                                                                     state.data());
         if (i1 < P.n) {  // park, as blind_rotate_wide_kernel does: each half the words it owns
           for (int r = 0; r < EC / 2; ++r) {
             const int j = (r + q * (EC / 2)) * 64 + lane;
@@ -475,13 +478,24 @@ int emu_blind_rotate_wide(u32 n, u32 k, u32 logn, u32 log_p, u32 padding, u32 lo
   PbsParams P = make_params(n, k, logn, log_p, padding, log_base, levels);
   typedef FftField FF;
   const FF::elem* key = (const FF::elem*)bsk;
-  if (logn == 9 && k == 1) blind_rotate_wide<FF, 9, 1>(P, batch, lwe, tv, tv_stride, key, out_glwe, out_lwe);
-  else if (logn == 9 && k == 2) blind_rotate_wide<FF, 9, 2>(P, batch, lwe, tv, tv_stride, key, out_glwe, out_lwe);
-  else if (logn == 10 && k == 1) blind_rotate_wide<FF, 10, 1>(P, batch, lwe, tv, tv_stride, key, out_glwe, out_lwe);
-  else if (logn == 10 && k == 2) blind_rotate_wide<FF, 10, 2>(P, batch, lwe, tv, tv_stride, key, out_glwe, out_lwe);
+#define WIDE_LEVELS(LOGN_, K_)                                                                                   \
+  do {                                                                                                           \
+    const int lv = g_wide_key_ring ? (int)levels : 0;                                                            \
+    if (lv == 2) blind_rotate_wide<FF, LOGN_, K_, 2>(P, batch, lwe, tv, tv_stride, key, out_glwe, out_lwe);       \
+    else if (lv == 3) blind_rotate_wide<FF, LOGN_, K_, 3>(P, batch, lwe, tv, tv_stride, key, out_glwe, out_lwe);  \
+    else if (lv == 4) blind_rotate_wide<FF, LOGN_, K_, 4>(P, batch, lwe, tv, tv_stride, key, out_glwe, out_lwe);  \
+    else if (lv == 6) blind_rotate_wide<FF, LOGN_, K_, 6>(P, batch, lwe, tv, tv_stride, key, out_glwe, out_lwe);  \
+    else blind_rotate_wide<FF, LOGN_, K_, 0>(P, batch, lwe, tv, tv_stride, key, out_glwe, out_lwe);               \
+  } while (0)
+  if (logn == 9 && k == 1) WIDE_LEVELS(9, 1);
+  else if (logn == 9 && k == 2) WIDE_LEVELS(9, 2);
+  else if (logn == 10 && k == 1) WIDE_LEVELS(10, 1);
+  else if (logn == 10 && k == 2) WIDE_LEVELS(10, 2);
   else return 1;
+#undef WIDE_LEVELS
   return 0;
 }
+void emu_set_wide_key_ring(int on) { g_wide_key_ring = on != 0; }
 
 int emu_external_product(int field, int g, u32 k, u32 logn, u32 log_base, u32 levels, const void* ggsw,
                          const u32* glwe, u32* out) {

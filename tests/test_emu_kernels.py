@@ -444,12 +444,14 @@ WIDE_CASES = [
 
 
 @pytest.mark.parametrize("k,logn,n,pbs,log_p", WIDE_CASES)
-@pytest.mark.parametrize("segments", [1, 2])
-def test_wide_team_blind_rotation_vs_oracle(emu, oracle, k, logn, n, pbs, log_p, segments):
+@pytest.mark.parametrize("segments,key_ring", [(1, 1), (2, 1), (1, 0)])
+def test_wide_team_blind_rotation_vs_oracle(emu, oracle, k, logn, n, pbs, log_p, segments, key_ring):
     """pbs_wave.h::blind_rotate_team_wide -- the latency shape for small batches: 2 (k+1) waves per sample, wave (c, q)
     transforms half of polynomial c's digit levels, accumulates key part q of column c over all rows, inverse-transforms
     that one accumulator and adds lift << 16 q into the accumulator polynomial.  Same words as the reference's loop
-    (oracle trace): a~ = 0 and b~ -> 2N rows, per-sample test vectors, whole and segmented rotations."""
+    (oracle trace): a~ = 0 and b~ -> 2N rows, per-sample test vectors, whole and segmented rotations; with the KEY RING
+    (pbs_wave.h::WideKeyRing: the instantiations for 2, 3, 4 and 6 levels keep whole rows of key tiles in registers and refill
+    a slot with the next row -- of the next CMUX's GGSW at the end of a product) and with the generic kernel's chunked loads."""
     if not field_exact(FFT, k, logn, pbs):
         pytest.skip("outside the rounding bound")
     params = oracle.Params(k, logn, n, oracle.Decomposer(*pbs), log_p=log_p)
@@ -464,11 +466,13 @@ def test_wide_team_blind_rotation_vs_oracle(emu, oracle, k, logn, n, pbs, log_p,
     glwe = np.zeros((batch, k + 1, params.N), dtype=np.uint32)
     ext = np.zeros((batch, params.big_n + 1), dtype=np.uint32)
     emu.emu_set_segments(segments)
+    emu.emu_set_wide_key_ring(key_ring)
     try:
         rc = emu.emu_blind_rotate_wide(n, k, logn, log_p, 1, pbs[0], pbs[1], C.c_size_t(batch), p32(lwe), p32(tvs),
                                        C.c_size_t(params.N), p64(spec), p32(glwe), p32(ext))
     finally:
         emu.emu_set_segments(1)
+        emu.emu_set_wide_key_ring(1)
     assert rc == 0
     for b in range(batch):
         _, tr = oracle.bootstrap(params, lwe[b], bsk, ksk, tvs[b], trace=True)

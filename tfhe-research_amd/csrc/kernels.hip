@@ -388,13 +388,16 @@ struct WideCfg {
   static __host__ __device__ size_t lds(u32 levels) { return kTwBytes + row_buffers(levels) * kRowBytes + (size_t)(K + 1) * N * 4; }
 };
 
-// (waves per SIMD the register allocation aims at: with 1 the compiler takes 260 registers at N = 1024, k = 1 and spills 67
-// at k = 2, whose six waves put two on two of the SIMDs anyway)
-#ifndef TFHE_WIDE_MIN_WAVES
-#define TFHE_WIDE_MIN_WAVES 2
+// Key ring of the wide team (pbs_wave.h::WideKeyRing): rows of a wave's key tiles held in registers ahead of time.
+// LEVELS > 0 instantiates the kernel for that level count (the ring's slots are compile-time); LEVELS = 0 is the generic
+// kernel (run-time level count, key chunks one ahead).  Register budget: a k = 1 team is four waves, one per SIMD, and
+// one team per CU is all its LDS allows -- a wave may use the SIMD's whole file (512 registers: the allocator takes
+// AGPRs beyond 256): 224 for the ring; a k = 2 team's six waves put two on two of the SIMDs: 256 each, 112 for the ring.
+#ifndef TFHE_WIDE_MIN_WAVES_K2
+#define TFHE_WIDE_MIN_WAVES_K2 2
 #endif
-template <class F, int LOGN, int K>
-__global__ void __launch_bounds__((WideCfg<F, LOGN, K>::kThreads), TFHE_WIDE_MIN_WAVES)
+template <class F, int LOGN, int K, int LEVELS>
+__global__ void __launch_bounds__((WideCfg<F, LOGN, K>::kThreads), (K == 1 && LEVELS > 0 ? 1 : TFHE_WIDE_MIN_WAVES_K2))
 blind_rotate_wide_kernel(PbsParams P, const typename F::elem* __restrict__ tw, const u32* __restrict__ lwe_in, size_t batch,
                          const u32* __restrict__ tv, size_t tv_stride, const typename F::elem* __restrict__ bsk,
                          u32* glwe_out, u32* __restrict__ lwe_extracted, u32 i_begin, u32 i_end, u32* glwe_state) {
@@ -415,7 +418,8 @@ blind_rotate_wide_kernel(PbsParams P, const typename F::elem* __restrict__ tw, c
   w.twg_ = tw;
   const size_t sample = blockIdx.x;  // grid = batch
   const u32* resume = i_begin > 0 ? glwe_state + sample * (size_t)(K + 1) * N : nullptr;
-  blind_rotate_team_wide<F, LOGN, K>(w, P, lwe_in + sample * (P.n + 1), tv + sample * tv_stride, bsk, i_begin, i_end, resume);
+  blind_rotate_team_wide<F, LOGN, K, LEVELS, wide_ring_rows<LOGN, K, LEVELS>()>(w, P, lwe_in + sample * (P.n + 1), tv + sample * tv_stride, bsk,
+                                                                               i_begin, i_end, resume);
   (void)batch;
   // each half stores the words it loaded: registers [q EC/2, (q + 1) EC/2) of polynomial c
   const int tid = w.tid(), me = w.group(), q = w.half();
@@ -1034,13 +1038,31 @@ hipError_t launch_blind_rotate_wide(hipStream_t s, const PbsParams& P, const typ
     return hipErrorInvalidValue;
   } else {
     using W = WideCfg<F, LOGN, K>;
-    auto kern = blind_rotate_wide_kernel<F, LOGN, K>;
-    static std::atomic<unsigned long long> lds_done{0};
-    hipError_t e = allow_lds(kern, (size_t)160 * 1024, lds_done);  // the size depends on the level count: allow the CU's whole LDS
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(W::kThreads), W::lds(P.levels), s, P, tw, lwe_in, batch, tv, tv_stride,
-                       bsk, glwe_out, lwe_extracted, 0u, P.n, static_cast<u32*>(nullptr));
-    return hipGetLastError();
+    // the level counts with a key-ring instantiation (the BASELINE configurations' 2, 3, 6 and the full-word 4); any other
+    // count runs the generic kernel
+    auto launch = [&](auto levels_c) -> hipError_t {
+      constexpr int LEVELS = decltype(levels_c)::value;
+      auto kern = blind_rotate_wide_kernel<F, LOGN, K, LEVELS>;
+      static std::atomic<unsigned long long> lds_done{0};
+      hipError_t e = allow_lds(kern, (size_t)160 * 1024, lds_done);  // the size depends on the level count: allow the CU's whole LDS
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(W::kThreads), W::lds(P.levels), s, P, tw, lwe_in, batch, tv, tv_stride,
+                         bsk, glwe_out, lwe_extracted, 0u, P.n, static_cast<u32*>(nullptr));
+      return hipGetLastError();
+    };
+#ifndef TFHE_WIDE_KEY_RING
+#define TFHE_WIDE_KEY_RING 1
+#endif
+    if (TFHE_WIDE_KEY_RING) {
+      switch (P.levels) {
+        case 2: return launch(IntC<2>{});
+        case 3: return launch(IntC<3>{});
+        case 4: return launch(IntC<4>{});
+        case 6: return launch(IntC<6>{});
+        default: break;
+      }
+    }
+    return launch(IntC<0>{});
   }
 }
 
@@ -1142,7 +1164,13 @@ template <class F, int LOGN, int K>
 hipError_t launch_blind_rotate_bmmp(hipStream_t s, const PbsParams& P, const void* tw_v, const u32* lwe_in,
                                     size_t batch, const u32* tv, size_t tv_stride, const void* bsk_v,
                                     u32* glwe_out, u32* lwe_extracted) {
-  if constexpr (LOGN != 9 || !field_shape_ok<F, LOGN>() || !(F::kId == GlField::kId || F::kId == Fp49Field::kId)) {
+  // (TFHE_BMMP_FFT: A/B builds only -- the unrolled rotation in the complex transform, measured and not offered:
+  // profiles/r04_kernel_ab.txt)
+#ifndef TFHE_BMMP_FFT
+#define TFHE_BMMP_FFT 0
+#endif
+  if constexpr (LOGN != 9 || !field_shape_ok<F, LOGN>() ||
+                !(F::kId == GlField::kId || F::kId == Fp49Field::kId || (TFHE_BMMP_FFT && F::kId == FftField::kId))) {
     return hipErrorInvalidValue;  // shape_supported_bmmp() / field_supported_bmmp() keep callers away
   } else {
     using C = TeamCfg<F, LOGN, K, 1>;
@@ -1256,7 +1284,7 @@ bool shape_supported_bmmp(u32 log_n, u32 k) { return log_n == 9 && (k == 1 || k 
 // mode is at least even with the loop: Goldilocks (+10 % at the reference's default parameters) and the single-spectrum
 // 49-bit field (-5 %, 17-23 spilled registers).  In the two-spectra fields it ran 1.9-3.4x slower than the loop on 50-172
 // spilled registers (profiles/r02_kernel_ab.txt, r02_h_isa_resources_all_kernels.txt): not instantiated, refused at load.
-bool field_supported_bmmp(int field) { return field == kFieldGoldilocks || field == kFieldFp49; }
+bool field_supported_bmmp(int field) { return field == kFieldGoldilocks || field == kFieldFp49 || (TFHE_BMMP_FFT && field == kFieldFft); }
 
 int field_parts(int field) { return (field == kFieldGoldilocks || field == kFieldFp49) ? 1 : 2; }
 

@@ -641,8 +641,59 @@ TFHE_HD void blind_rotate_team(const Ctx& c, const PbsParams& P, const u32* lwe 
 //
 // Ctx additionally provides: half() (q), row_buffer(r): the buffer of digit row r; scratch() is the wave's own buffer.
 // ---------------------------------------------------------------------------------------------
-template <class F, int LOGN, int K, class Ctx, class Src, class Out>
-TFHE_HD void external_product_team_wide(const Ctx& c, const PbsParams& P, const typename F::elem* ggsw, Src src, Out out) {
+// Key delivery.  LEVELS = 0: the level count is a run-time value; the tiles of my (column, part) come in chunks of CH
+// elements, double-buffered in registers, one chunk ahead of the arithmetic (any parameter set).  LEVELS > 0 (the level
+// count the kernel was instantiated for; P.levels must equal it): the KEY RING.  One wave alone on its SIMD has nobody to
+// hide a load behind, and a chunk's arithmetic (16 fused multiply-adds) is a seventh of an L2 round trip: with chunks one
+// ahead the multiply-accumulate of an idle chip waits for the key ~24 times per CMUX (profiles/r04_a_batch_sweep*: 6.8 us
+// per CMUX at N = 1024, k = 1 against 2.7 us of instructions).  The register file is the one store big enough to take a
+// GGSW ahead of time (4 waves x 192 registers x 256 B = the 197 KB of cfg2's GGSW): the ring holds RING whole rows
+// (E elements each) of my tiles, RING | (K+1) LEVELS; row m of a product sits in slot m % RING; as soon as a row has
+// been multiplied its slot is refilled with row m + RING -- of this product, or of the NEXT CMUX's GGSW (`ggsw_next`),
+// so the loads of a CMUX travel under the previous CMUX's arithmetic and the forward transforms in between.
+// The ring lives in the caller (it survives from product to product): WideKeyRing.
+template <class F, int LOGN, int K, int LEVELS, int RING>
+struct WideKeyRing {
+  static constexpr int E = NttShape<LOGN - 1, 1>::kE;
+  static constexpr int R = (K + 1) * LEVELS;
+  static constexpr int kRing = RING;
+  static_assert(LEVELS > 0 && RING > 0 && R % RING == 0, "the ring holds a divisor of the product's rows");
+  typename F::elem slot[RING][E];
+  // row m (multiply-accumulate order: level = m / (K+1), source polynomial = m % (K+1)) of the GGSW at `ggsw`, for
+  // output column `me` and key part q
+  template <int M>
+  TFHE_HD void load(const typename F::elem* ggsw, int me, int q, int lane) {
+    constexpr int level = M / (K + 1), sp = M % (K + 1);
+    const typename F::elem* tile = ggsw + ((((size_t)sp * LEVELS + level) * (K + 1) + me) * 2 + q) * ((size_t)1 << (LOGN - 1));
+#pragma unroll
+    for (int r = 0; r < E; ++r) slot[M % RING][r] = tile[spectrum_slot<LOGN - 1, 1, (int)sizeof(typename F::elem)>(lane, r)];
+  }
+  // before the first product: rows 0 .. RING-1
+  TFHE_HD void prime(const typename F::elem* ggsw, int me, int q, int lane) {
+    static_for<0, RING>([&](auto m_c) { load<decltype(m_c)::value>(ggsw, me, q, lane); });
+  }
+};
+struct NoKeyRing {
+  static constexpr int kRing = 1;
+};
+// rows the ring of a (LOGN, K, LEVELS) kernel holds: the largest divisor of the product's (K+1) LEVELS rows that the register
+// budget takes (kernels.hip explains the budget: 224 registers for a k = 1 team's waves, 112 for a k = 2 team's)
+constexpr int largest_divisor_upto(int n, int cap) {
+  int best = 1;
+  for (int d = 1; d <= n && d <= cap; ++d)
+    if (n % d == 0) best = d;
+  return best;
+}
+template <int LOGN, int K, int LEVELS>
+constexpr int wide_ring_rows() {
+  constexpr int E = NttShape<LOGN - 1, 1>::kE;
+  return LEVELS == 0 ? 0 : largest_divisor_upto((K + 1) * LEVELS, (K == 1 ? 224 : 112) / (4 * E));
+}
+
+
+template <class F, int LOGN, int K, int LEVELS = 0, class Ring = NoKeyRing, class Ctx, class Src, class Out>
+TFHE_HD void external_product_team_wide(const Ctx& c, const PbsParams& P, const typename F::elem* ggsw,
+                                        const typename F::elem* ggsw_next, Ring& ring, Src src, Out out) {
   typedef typename F::elem elem;
   static_assert(F::kParts == 2 && F::kLogShrink == 1 && F::kCoeffs == 2, "the complex transform: two key parts, two coefficients per element");
   constexpr int LT = LOGN - 1;
@@ -650,12 +701,14 @@ TFHE_HD void external_product_team_wide(const Ctx& c, const PbsParams& P, const 
   constexpr int EC = 2 * E;
   constexpr int T = 64;
   constexpr int N = 1 << LT;  // transform elements per polynomial
+  constexpr bool RINGED = LEVELS > 0;
   const int lane = c.tid();
   const int me = c.group();
   const int q = c.half();
+  const u32 levels = RINGED ? (u32)LEVELS : P.levels;
   // levels counted from the least significant limb (t), as the digit chain runs; level index = levels - 1 - t
-  const u32 split = (P.levels + 1u) / 2u;
-  const u32 t_begin = q == 0 ? 0u : split, t_end = q == 0 ? split : P.levels;
+  const u32 split = (levels + 1u) / 2u;
+  const u32 t_begin = q == 0 ? 0u : split, t_end = q == 0 ? split : levels;
 
   TopConsts<F, LT, 1, true> ftop;
   ftop.issue(c.twiddles_uniform());
@@ -665,22 +718,24 @@ TFHE_HD void external_product_team_wide(const Ctx& c, const PbsParams& P, const 
   for (int r = 0; r < EC; ++r) v[r] = round_value_fast(src(r * T + lane), rc);
   ftop.ready();
 
-  // key chunks of my (column, part): row by row, CH elements at a time, double-buffered in registers
+  // (no ring) key chunks of my (column, part): row by row, CH elements at a time, double-buffered in registers
   // (an even number of chunks per level keeps the staging buffer of a chunk a compile-time constant across levels)
   constexpr int CH0 = E < 4 ? E : 4;
   constexpr int CH = (((K + 1) * (E / CH0)) % 2 == 0) ? CH0 : CH0 / 2;
   constexpr int PIECES = E / CH;
   constexpr int CHK = (K + 1) * PIECES;  // chunks per level: source polynomial sp, then the piece of its spectrum
-  elem kbuf[2][CH];
+  elem kbuf[RINGED ? 1 : 2][RINGED ? 1 : CH];
   auto load_chunk = [&](u32 level, auto ci_c, int buf) {
     constexpr int ci = decltype(ci_c)::value;
     constexpr int sp = ci / PIECES, r0 = (ci % PIECES) * CH;
-    const elem* tile = ggsw + ((((size_t)sp * P.levels + level) * (K + 1) + me) * 2 + q) * N;
+    const elem* tile = ggsw + ((((size_t)sp * levels + level) * (K + 1) + me) * 2 + q) * N;
 #pragma unroll
-    for (int r = 0; r < CH; ++r) kbuf[buf][r] = tile[spectrum_slot<LT, 1, (int)sizeof(elem)>(lane, r0 + r)];
+    for (int r = 0; r < CH; ++r) kbuf[RINGED ? 0 : buf][RINGED ? 0 : r] = tile[spectrum_slot<LT, 1, (int)sizeof(elem)>(lane, r0 + r)];
   };
-  load_chunk(0u, IntC<0>{}, 0);  // in flight under the forward transforms
-  c.compiler_fence();
+  if constexpr (!RINGED) {
+    load_chunk(0u, IntC<0>{}, 0);  // in flight under the forward transforms
+    c.compiler_fence();
+  }
 
 #pragma unroll 1
   for (u32 t = 0; t < t_end; ++t) {
@@ -695,7 +750,7 @@ TFHE_HD void external_product_team_wide(const Ctx& c, const PbsParams& P, const 
       work[r] = F::from_digits(dg);
     }
     if (t < t_begin) continue;  // (wave-uniform) my twin's limb: only the carries were needed
-    const u32 row = (u32)me * P.levels + (P.levels - 1u - t);
+    const u32 row = (u32)me * levels + (levels - 1u - t);
     // transposes in my own buffer (fixed addresses: the swizzled offsets stay loop invariants), the spectrum then goes
     // to its row's buffer, which nobody has read since barrier B of the previous product
     ntt_forward<F, LT, 1, true, true>(c, work, ftop);
@@ -710,26 +765,45 @@ TFHE_HD void external_product_team_wide(const Ctx& c, const PbsParams& P, const 
   elem accum[E];
 #pragma unroll
   for (int r = 0; r < E; ++r) accum[r] = F::zero();
-#pragma unroll 1
-  for (u32 level = 0; level < P.levels; ++level) {
-    static_for<0, CHK>([&](auto ci_c) {
-      constexpr int ci = decltype(ci_c)::value;
-      constexpr int sp = ci / PIECES, r0 = (ci % PIECES) * CH;
-      constexpr int cur = ci % 2;
-      static_assert(CHK % 2 == 0, "an even number of chunks per level keeps the buffer parity static");
-      if constexpr (ci + 1 < CHK) {
-        load_chunk(level, IntC<ci + 1>{}, (ci + 1) % 2);
-      } else {
-        if (level + 1u < P.levels) load_chunk(level + 1u, IntC<0>{}, 0);
-      }
-      const elem* spec = c.row_buffer((int)((u32)sp * P.levels + level));
-      elem d[CH];
+  if constexpr (RINGED) {
+    constexpr int R = (K + 1) * LEVELS;
+    constexpr int RING_ROWS = Ring::kRing;
+    static_for<0, R>([&](auto m_c) {
+      constexpr int m = decltype(m_c)::value;
+      constexpr int level = m / (K + 1), sp = m % (K + 1);
+      const elem* spec = c.row_buffer(sp * LEVELS + level);
+      elem d[E];
 #pragma unroll
-      for (int r = 0; r < CH; ++r) d[r] = spec[exchange_slot<LT, 1>(lane, r0 + r)];
-      c.compiler_fence();  // keep the next chunk's loads above this chunk's arithmetic
+      for (int r = 0; r < E; ++r) d[r] = spec[exchange_slot<LT, 1>(lane, r)];
 #pragma unroll
-      for (int r = 0; r < CH; ++r) accum[r0 + r] = F::mul_add(d[r], kbuf[cur][r], accum[r0 + r]);
+      for (int r = 0; r < E; ++r) accum[r] = F::mul_add(d[r], ring.slot[m % RING_ROWS][r], accum[r]);
+      c.compiler_fence();  // the refill below stays behind this row's arithmetic: its registers are the row's
+      // refill the slot: row m + RING of this product, or row m + RING - R of the next CMUX's GGSW
+      if constexpr (m + RING_ROWS < R) ring.template load<m + RING_ROWS>(ggsw, me, q, lane);
+      else ring.template load<m + RING_ROWS - R>(ggsw_next, me, q, lane);
     });
+  } else {
+#pragma unroll 1
+    for (u32 level = 0; level < levels; ++level) {
+      static_for<0, CHK>([&](auto ci_c) {
+        constexpr int ci = decltype(ci_c)::value;
+        constexpr int sp = ci / PIECES, r0 = (ci % PIECES) * CH;
+        constexpr int cur = ci % 2;
+        static_assert(CHK % 2 == 0, "an even number of chunks per level keeps the buffer parity static");
+        if constexpr (ci + 1 < CHK) {
+          load_chunk(level, IntC<ci + 1>{}, (ci + 1) % 2);
+        } else {
+          if (level + 1u < levels) load_chunk(level + 1u, IntC<0>{}, 0);
+        }
+        const elem* spec = c.row_buffer((int)((u32)sp * levels + level));
+        elem d[CH];
+#pragma unroll
+        for (int r = 0; r < CH; ++r) d[r] = spec[exchange_slot<LT, 1>(lane, r0 + r)];
+        c.compiler_fence();  // keep the next chunk's loads above this chunk's arithmetic
+#pragma unroll
+        for (int r = 0; r < CH; ++r) accum[r0 + r] = F::mul_add(d[r], kbuf[RINGED ? 0 : cur][RINGED ? 0 : r], accum[r0 + r]);
+      });
+    }
   }
   // (no barrier here: the inverse transform works in my own buffer and the accumulator polynomial is only read before
   // barrier A; the row buffers are written again after barrier C)
@@ -746,7 +820,8 @@ TFHE_HD void external_product_team_wide(const Ctx& c, const PbsParams& P, const 
 }
 
 // Blind rotation of ONE sample by a wide team (bootstrapping.rs:67-105); segments as blind_rotate_team_multi.
-template <class F, int LOGN, int K, class Ctx>
+// LEVELS / RING: the key ring (above); LEVELS = 0: run-time level count, chunked key loads.
+template <class F, int LOGN, int K, int LEVELS = 0, int RING = 0, class Ctx>
 TFHE_HD void blind_rotate_team_wide(const Ctx& c, const PbsParams& P, const u32* lwe /* n+1 */, const u32* tv /* N, un-encoded */,
                                     const typename F::elem* bsk /* prepared */, u32 i_begin, u32 i_end,
                                     const u32* resume /* [K+1][N], read if i_begin > 0 */) {
@@ -756,6 +831,12 @@ TFHE_HD void blind_rotate_team_wide(const Ctx& c, const PbsParams& P, const u32*
   const int me = c.group();
   const int q = c.half();
   u32* acc = c.acc();
+  const u32 levels = LEVELS > 0 ? (u32)LEVELS : P.levels;
+  const size_t ggsw_words = (size_t)(K + 1) * levels * (K + 1) * 2 * (N >> 1);  // elements
+  typename std::conditional<(LEVELS > 0), WideKeyRing<F, LOGN, K, (LEVELS > 0 ? LEVELS : 1), (RING > 0 ? RING : 1)>, NoKeyRing>::type ring;
+  if constexpr (LEVELS > 0) {
+    if (i_begin < i_end) ring.prime(bsk + (size_t)i_begin * ggsw_words, me, q, lane);  // under the accumulator's set-up
+  }
   // each half fills (and, in the kernel's epilogue, stores) half of the polynomial's words: registers [q EC/2, (q+1) EC/2)
   if (i_begin > 0) {
     const u32* from = resume + (size_t)me * N;
@@ -779,14 +860,16 @@ TFHE_HD void blind_rotate_team_wide(const Ctx& c, const PbsParams& P, const u32*
     }
   }
   c.team_sync();
-  const size_t ggsw_words = (size_t)(K + 1) * P.levels * (K + 1) * 2 * (N >> 1);  // elements
 #pragma unroll 1
   for (u32 i = i_begin; i < i_end; ++i) {
     const u32 a_tilde = c.uniform(switch_modulus_2n(lwe[i], LOGN));
     auto src = [&](int j) -> u32 { return monomial_coeff<LOGN>(acc, j, a_tilde) - acc[j]; };
     // every rotated read of acc happens before barrier A, every update after it: in place is safe
     auto out = [&](int half, int j, u32 value) { c.lds_add(acc + j, value << (16 * half)); };
-    external_product_team_wide<F, LOGN, K>(c, P, bsk + (size_t)i * ggsw_words, src, out);
+    const typename F::elem* ggsw = bsk + (size_t)i * ggsw_words;
+    // the ring's refills of the last CMUX have no successor: they re-read this GGSW's first rows (valid memory, unused)
+    const typename F::elem* ggsw_next = i + 1 < i_end ? ggsw + ggsw_words : ggsw;
+    external_product_team_wide<F, LOGN, K, LEVELS>(c, P, ggsw, ggsw_next, ring, src, out);
     c.team_sync();  // B: both halves of every column have added their part; all reads of the spectra are over
   }
 }

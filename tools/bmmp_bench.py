@@ -18,11 +18,16 @@ rw = lambda *s: torch.randint(-(1 << 31), (1 << 31) - 1, s, dtype=torch.int32, d
 lw, kk = rw(batch, n + 1), rw(*P.ksk_shape())
 keys = {"loop": rw(*P.bsk_shape()), "bmmp": rw(*P.bsk_bmmp_shape())}
 tvd = torch.from_numpy(m.construct_identity_test_vector(P).astype(np.int32)).to(dev)
-for name, be in (("fp64-p49", m.BACKEND_FP64_P49), ("goldilocks", m.BACKEND_GOLDILOCKS)):  # the backends that offer BMMP
+# the backends that offer BMMP; BMMP_BENCH_BACKENDS=fp64-fft adds the complex transform for dev builds with -DTFHE_BMMP_FFT=1
+BACKENDS = [("fp64-p49", m.BACKEND_FP64_P49), ("goldilocks", m.BACKEND_GOLDILOCKS)]
+if "fp64-fft" in os.environ.get("BMMP_BENCH_BACKENDS", ""):
+    BACKENDS = [("fp64-fft", m.BACKEND_FP64_FFT)]
+for name, be in BACKENDS:
     try:
         ctx = m.Context(P, backend=be)
     except m.TfheError:
         continue
+    ctx.set_kernel_shape(m.SHAPE_TEAM)
     ctx.reserve(batch); ctx.set_timing(True)
     out = torch.empty_like(lw)
     line = [f"{which} batch {batch} {ctx.backend:<12}"]

@@ -13,6 +13,7 @@ which = sys.argv[1]
 BACKEND = getattr(m, os.environ.get('DEV_BACKEND', 'BACKEND_FP64'))
 cfg = {"cfg1": (1, 9, 500, (8, 2), 4096), "cfg2": (1, 10, 630, (7, 3), 4096), "cfg3": (2, 9, 722, (4, 6), 4096), "cfg5": (2, 11, 630, (8, 4), 1024)}[which]
 k, logn, n, pbs, batch = cfg
+batch = int(os.environ.get("DEV_BATCH", batch))
 # parity on a short key first
 ps = orc.Params(k, logn, 4, orc.Decomposer(*pbs)); pp = m.TfheParams(k, logn, 4, m.DecomposerParams(*pbs))
 lwe, bsk, ksk, tv = orc.synthetic_inputs(ps, 5, cfg_index=3)
@@ -26,13 +27,15 @@ rw = lambda *s: torch.randint(-(1 << 31), (1 << 31) - 1, s, dtype=torch.int32, d
 lw, bk, kk = rw(batch, n + 1), rw(*P.bsk_shape()), rw(*P.ksk_shape())
 tvd = torch.from_numpy(m.construct_identity_test_vector(P).astype(np.int32)).to(dev)
 ctx = m.Context(P, backend=BACKEND); ctx.use_torch_stream(); ctx.load_bootstrapping_key(bk, kk); ctx.reserve(batch); ctx.set_timing(True)
+ctx.set_kernel_shape({"auto": m.SHAPE_AUTO, "wide": m.SHAPE_WIDE, "team": m.SHAPE_TEAM}[os.environ.get("DEV_SHAPE", "auto")])
+if os.environ.get("DEV_ALIGNED"): ctx.set_decomposer_alignment(True)
 out = torch.empty_like(lw)
 ctx.bootstrap(lw, tvd, out=out); torch.cuda.synchronize()
 ts = []
 for _ in range(3):
     ctx.bootstrap(lw, tvd, out=out); ts.append(ctx.last_kernel_ms())
 br = np.mean([t[0] for t in ts]); ks = np.mean([t[1] for t in ts])
-print(f"{os.path.basename(os.environ.get('TFHE_HIP_LIB','default'))} {which}: parity {ok} blind_rotate {br:.2f} ms key_switch {ks:.2f} ms -> {batch / ((br + ks) * 1e-3):.0f} PBS/s", flush=True)
+print(f"{os.path.basename(os.environ.get('TFHE_HIP_LIB','default'))} {which} shape={os.environ.get('DEV_SHAPE', 'auto')} batch={batch}: parity {ok} blind_rotate {br:.2f} ms key_switch {ks:.2f} ms -> {batch / ((br + ks) * 1e-3):.0f} PBS/s", flush=True)
 # key switch parity on random data (oracle)
 rng = np.random.default_rng(1)
 pk = orc.Params(k, logn, 37, orc.Decomposer(*pbs), orc.Decomposer(4, 5))

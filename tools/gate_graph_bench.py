@@ -47,9 +47,11 @@ for inst in (64, 1024, 4096):
             gc.stream.synchronize()
             eager = (time.perf_counter() - t0) / 3 * 1e3
         gc(x)
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(3):
             gc(x)
+        torch.cuda.synchronize()   # (round 4: without this the "graph" column timed three graph LAUNCHES, not three replays)
         graph = (time.perf_counter() - t0) / 3 * 1e3
         print(f"{inst} {eager:.2f} {graph:.2f} {inst * pbs_gates / (graph * 1e-3):.0f}")
         ctx.set_stream(None)
