@@ -59,3 +59,61 @@ def test_system_rng_is_the_default_source_of_key_material():
     import inspect
     src = inspect.getsource(m.Context.generate_keys) + inspect.getsource(m.Context.encrypt_bits)
     assert "SystemRng()" in src and "default_rng" not in src
+
+
+class _ClearContext:
+    """Stands in for a Context on CPU tensors: a 'ciphertext' is one word holding the bit (width 1), a test vector is
+    the gate's truth table in its first four words, bootstrap(x, tvs) = tvs[row][x[row]] -- enough to check that the
+    planner feeds every gate the right operands, order (2 * ct1 + ct0, boolean.rs:18) and table, merged or not."""
+    io_dim = 0
+
+    class params:
+        N = 8
+
+    def __init__(self):
+        self.calls = []
+
+    def lwe_linear(self, c0, ct0, c1=0, ct1=None, out=None):
+        return c0 * ct0 + (c1 * ct1 if ct1 is not None else 0)
+
+    def bootstrap(self, x, tvs):
+        import torch
+        self.calls.append(("bootstrap", int(x.shape[0])))
+        rows = torch.arange(x.shape[0])
+        return tvs[rows, x[:, 0].long()].reshape(-1, 1).to(x.dtype)
+
+    def gate(self, truth, ct0, ct1, out=None):
+        import torch
+        self.calls.append(("gate", int(ct0.shape[0])))
+        t = torch.tensor(truth, dtype=ct0.dtype)
+        return t[(2 * ct1 + ct0)[:, 0].long()].reshape(-1, 1)
+
+
+def test_a_levels_two_input_gates_share_one_bootstrap_call(monkeypatch):
+    """gates.plan merges all two-input gates of a level into ONE step (per-row test vectors); the merged evaluation equals
+    the clear evaluation for every input of a 4-bit adder; above MERGE_LIMIT rows the per-truth-table calls come back"""
+    import numpy as np
+    import torch
+    g = gates_mod()
+    circuit, out = g.ripple_carry_adder(4)
+    steps = g.plan(circuit, torch.device("cpu"))
+    assert len(steps) == len(circuit.levels())              # one step per level: nothing but two-input gates here
+    assert any(st.kind == "gate2" and len(st.parts) >= 2 for st in steps)
+    ctx = _ClearContext()
+    table = torch.zeros((len(g._KINDS), 8), dtype=torch.int32)
+    for i, kind in enumerate(g._KINDS):
+        table[i, :4] = torch.tensor(g.TRUTH[kind], dtype=torch.int32)
+    ctx._gate_tv_table = table
+    inputs = torch.tensor([[(a >> j) & 1 for j in range(4)] + [(b >> j) & 1 for j in range(4)]
+                           for a in range(16) for b in range(16)], dtype=torch.int32).reshape(256, 8, 1)
+    wires = g.evaluate(ctx, circuit, inputs, steps)[:, :, 0].numpy()
+    for row, bits in zip(wires, inputs[:, :, 0].tolist()):
+        assert row.tolist() == circuit.evaluate_clear(bits)
+    merged_calls = [c for c in ctx.calls if c[0] == "bootstrap"]
+    assert len(merged_calls) == sum(1 for st in steps if st.kind == "gate2")
+    # a full chip: the same plan falls back to one call per truth table
+    monkeypatch.setattr(g, "MERGE_LIMIT", 16)
+    ctx2 = _ClearContext()
+    ctx2._gate_tv_table = table
+    wires2 = g.evaluate(ctx2, circuit, inputs, steps)[:, :, 0].numpy()
+    assert np.array_equal(wires, wires2) and not any(c[0] == "bootstrap" for c in ctx2.calls)

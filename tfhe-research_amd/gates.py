@@ -5,8 +5,15 @@ bootstrap of 2*ct1 + ct0 with a test vector built from a closure (test_vector.rs
 gate is the same bootstrap with another truth table, a gate of m inputs is the bootstrap of
 sum_i 2^i * ct_i in a plaintext space of m bits (notes/Boolean Gates.md:2-11), and a gate's output
 is a fresh encryption of a bit, so gates chain.  This module evaluates a whole graph of such gates
-with every ciphertext staying in HBM: wires live in one device tensor, each level's gates that
-share a truth table go to the GPU as ONE batched call of the C ABI.
+with every ciphertext staying in HBM: wires live in one device tensor, and ALL two-input gates of a
+level -- whatever their truth tables -- go to the GPU as ONE bootstrap call with one test vector per
+ciphertext (tfhe_lwe_linear_batch_device for 2*ct1 + ct0, then tfhe_bootstrap_batch_device with
+tv[batch][N]: the reference's bootstrap() takes the test vector as an argument, bootstrapping.rs:64).
+A narrow circuit's level is a few hundred ciphertexts -- far fewer than the chip holds -- so what a level
+costs is the LATENCY of one blind rotation, and calls that run one after the other each pay it again:
+merged, a level of a 16-bit adder over 64 instances costs one rotation instead of up to three
+(profiles/r04_gate_graph_adder16_cfg3.txt).  Wide levels (more rows than MERGE_LIMIT) keep one call per
+truth table: the chip is full either way and a shared test vector saves the per-row table.
 
 Gate kinds
   and / or / nand / nor / xor / xnor   one PBS (tfhe_gate_batch_device)
@@ -30,6 +37,8 @@ TRUTH = {  # truth[(lhs << 1) | rhs], lhs = bit of ct1, rhs = bit of ct0 (boolea
     "xnor": (1, 0, 0, 1),
 }
 _ANDNOT = (0, 1, 0, 0)  # (NOT lhs) AND rhs
+_KINDS = tuple(TRUTH)      # row order of the per-context test-vector table
+MERGE_LIMIT = 8192         # rows (instances x gates of a level) up to which a level's two-input gates share one call
 
 
 @dataclass
@@ -142,6 +151,9 @@ class _Step:
     operands: list          # device index tensors, one per operand position (as listed in the gate)
     dst: object             # device index tensor of the output wires
     count: int
+    kinds: object = None    # "gate2" steps: device tensor, row of the test-vector table (index into _KINDS) per gate
+    parts: list = None      # "gate2" steps: the per-truth-table steps they replace (used above MERGE_LIMIT rows)
+    tv_rows: dict = field(default_factory=dict)   # instances -> per-row table indices (kinds repeated per instance)
 
 
 def plan(circuit: Circuit, device) -> List[_Step]:
@@ -155,11 +167,36 @@ def plan(circuit: Circuit, device) -> List[_Step]:
             kind = circuit.gates[g][0]
             key = (kind, len(circuit.gates[g]) - 1, circuit.luts.get(g))
             groups.setdefault(key, []).append(g)
+        two_input: List[_Step] = []
         for (kind, arity, truth), gs in groups.items():
             ops = [torch.tensor([circuit.gates[g][pos] for g in gs], device=device) for pos in range(1, arity + 1)]
             dst = torch.tensor([circuit.n_inputs + g for g in gs], device=device)
-            steps.append(_Step(kind, truth, ops, dst, len(gs)))
+            st = _Step(kind, truth, ops, dst, len(gs))
+            (two_input if kind in TRUTH else steps).append(st)
+        if len(two_input) == 1:
+            steps.append(two_input[0])
+        elif two_input:
+            # one step for all two-input gates of the level: operands and outputs concatenated, one table row per gate
+            merged = _Step("gate2", None, [torch.cat([st.operands[pos] for st in two_input]) for pos in range(2)],
+                           torch.cat([st.dst for st in two_input]), sum(st.count for st in two_input),
+                           kinds=torch.tensor([_KINDS.index(st.kind) for st in two_input for _ in range(st.count)], device=device),
+                           parts=two_input)
+            steps.append(merged)
     return steps
+
+
+def _tv_table(ctx, device):
+    """[len(_KINDS)][N] un-encoded test vectors of the six two-input truth tables (test_vector.rs:5-20), on the device,
+    built once per context"""
+    import numpy as np
+    import torch
+    from . import construct_test_vector_boolean
+    table = getattr(ctx, "_gate_tv_table", None)
+    if table is None or table.device != device:
+        rows = np.stack([construct_test_vector_boolean(ctx.params, TRUTH[k]) for k in _KINDS]).astype(np.uint32)
+        table = torch.from_numpy(rows.view(np.int32)).to(device)
+        ctx._gate_tv_table = table
+    return table
 
 
 def _run(ctx, steps: List[_Step], wires):
@@ -168,8 +205,22 @@ def _run(ctx, steps: List[_Step], wires):
     def operand(step, pos):
         return wires.index_select(1, step.operands[pos]).reshape(-1, width).contiguous()
 
+    def gate2(st):
+        return ctx.gate(TRUTH[st.kind], operand(st, 1), operand(st, 0))
+
     for st in steps:
-        if st.kind == "not":
+        if st.kind == "gate2":
+            if inst * st.count > MERGE_LIMIT:   # a full chip: one call per truth table, one shared test vector each
+                for part in st.parts:
+                    wires[:, part.dst] = gate2(part).reshape(inst, part.count, width)
+                continue
+            rows = st.tv_rows.get(inst)
+            if rows is None:
+                rows = st.tv_rows[inst] = st.kinds.repeat(inst)     # row (instance, gate): instance-major like operand()
+            tvs = _tv_table(ctx, wires.device).index_select(0, rows)
+            # boolean.rs:18: ct_in = 2 * ct1 + ct0 (gate tuple: (kind, wire of ct1, wire of ct0))
+            out = ctx.bootstrap(ctx.lwe_linear(1, operand(st, 1), 2, operand(st, 0)), tvs)
+        elif st.kind == "not":
             out = ctx.lwe_not(operand(st, 0))
         elif st.kind == "mux":
             sel, a, b = operand(st, 0), operand(st, 1), operand(st, 2)
