@@ -138,6 +138,8 @@ void poly_ntt(const typename F::elem* in, typename F::elem* out, int inverse) {
   });
 }
 
+int g_key_k = 0;  // GLWE dimension of the key being prepared: selects its layout (pbs_wave.h::key_layout_e); 0 = natural
+
 template <class F, int LOGN, int G>
 void bsk_prepare(size_t polys, const u32* src, typename F::elem* dst) {
   typedef typename F::elem elem;
@@ -145,9 +147,17 @@ void bsk_prepare(size_t polys, const u32* src, typename F::elem* dst) {
   if constexpr (!shape_ok<F, LOGN, G>()) std::abort();
   else {
     const elem n_inv = F::n_inv(LOGN - F::kLogShrink);
+    constexpr int PAIR_E = key_layout_e<F, LOGN, 1>();
     run_team<F>(LOGN, 1, G, [&](const HostWave<elem>& w) {
-      for (size_t i = 0; i < polys; ++i)
+      for (size_t i = 0; i < polys; ++i) {
+        if constexpr (PAIR_E != 0) {
+          if (g_key_k == 1) {
+            bsk_prepare_wave<F, LOGN, G, PAIR_E>(w, src + i * N, dst + i * (N >> F::kLogShrink) * F::kParts, n_inv);
+            continue;
+          }
+        }
         bsk_prepare_wave<F, LOGN, G>(w, src + i * N, dst + i * (N >> F::kLogShrink) * F::kParts, n_inv);
+      }
     });
   }
 }
@@ -344,6 +354,83 @@ void blind_rotate_wide(const PbsParams& P, size_t batch, const u32* lwe, const u
   for (auto& t : th) t.join();
 }
 
+// ---- the pair kernel (pbs_wave.h::blind_rotate_pair): ONE wave per sample, polynomial c in lanes 32 c .. 32 c + 31 ----
+template <class Elem>
+struct HostPairTeam {
+  int n, ns;
+  std::vector<Elem> buffers, tw, tw_natural;  // buffers: 2 x ns
+  std::vector<u32> acc;                       // 2 x n
+  pthread_barrier_t wave_bar;
+};
+template <class Elem>
+struct HostPairWave {
+  int lane_;
+  HostPairTeam<Elem>* t_;
+  int tid() const { return lane_ & 31; }
+  int group() const { return lane_ >> 5; }
+  void wave_sync() const { pthread_barrier_wait(&t_->wave_bar); }
+  void poly_sync() const { wave_sync(); }
+  void team_sync() const { wave_sync(); }
+  Elem* scratch() const { return t_->buffers.data() + (size_t)group() * t_->ns; }
+  const Elem* scratch_of(int half) const { return t_->buffers.data() + (size_t)half * t_->ns; }
+  u32* acc(int = 0) const { return t_->acc.data() + (size_t)group() * t_->n; }
+  const Elem* twiddles() const { return t_->tw.data(); }
+  const Elem* twiddles_uniform() const { return t_->tw_natural.data(); }
+  u32 uniform(u32 v) const { return v; }
+  void lds_add(u32* p, u32 v) const { *p += v; }
+  void compiler_fence() const {}
+};
+
+template <class F, int LOGN>
+void blind_rotate_pair_emu(const PbsParams& P, size_t batch, const u32* lwe, const u32* tv, size_t tv_stride,
+                           const typename F::elem* bsk, u32* out_glwe, u32* out_lwe) {
+  typedef typename F::elem elem;
+  constexpr int N = 1 << LOGN;
+  constexpr int LT = LOGN - F::kLogShrink;
+  constexpr int K = 1;
+  HostPairTeam<elem> team;
+  team.n = N;
+  team.ns = 1 << LT;
+  team.buffers.resize((size_t)2 * team.ns);
+  team.acc.resize((size_t)2 * N);
+  team.tw_natural.resize(ntt_twiddle_words(team.ns));
+  F::fill_twiddles(LT, team.tw_natural.data());
+  team.tw.resize(team.tw_natural.size());
+  for (int tid = 0; tid < 64; ++tid) ntt_stage_twiddles<LT, 0>(team.tw.data(), team.tw_natural.data(), tid, 64);
+  pthread_barrier_init(&team.wave_bar, nullptr, kWave);
+  std::vector<u32> state((size_t)2 * N);
+  auto body = [&](const HostPairWave<elem>& w) {
+    constexpr int T = 32, EC = N / T;
+    const int me = w.group(), tid = w.tid();
+    for (size_t b = 0; b < batch; ++b) {
+      const u32 per = (P.n + g_segments - 1) / g_segments;
+      for (u32 i0 = 0; i0 < P.n; i0 += per) {
+        const u32 i1 = i0 + per < P.n ? i0 + per : P.n;
+        blind_rotate_pair<F, LOGN>(w, P, lwe + b * (P.n + 1), tv + b * tv_stride, bsk, i0, i1, state.data());
+        if (i1 < P.n) {
+          for (int r = 0; r < EC; ++r) state[(size_t)me * N + r * T + tid] = w.acc()[r * T + tid];
+          w.wave_sync();
+        }
+      }
+      const u32* acc = w.acc();
+      for (int r = 0; r < EC; ++r) {
+        const int x = r * T + tid;
+        if (out_glwe) out_glwe[(b * (K + 1) + me) * N + x] = acc[x];
+        if (out_lwe && me < K) out_lwe[b * ((size_t)K * N + 1) + me * N + x] = (x == 0) ? acc[0] : (0u - acc[N - x]);
+      }
+      if (out_lwe && me == K && tid == 0) out_lwe[b * ((size_t)K * N + 1) + K * N] = acc[0];
+      w.wave_sync();
+    }
+  };
+  std::vector<std::thread> th;
+  for (int l = 0; l < kWave; ++l)
+    th.emplace_back([&, l] {
+      HostPairWave<elem> ctx{l, &team};
+      body(ctx);
+    });
+  for (auto& t : th) t.join();
+}
+
 bool g_aligned = false;  // decomposer alignment extension (tfhe_hip.h)
 
 PbsParams make_params(u32 n, u32 k, u32 log_n, u32 log_p, u32 padding, u32 log_base, u32 levels) {
@@ -496,6 +583,15 @@ int emu_blind_rotate_wide(u32 n, u32 k, u32 logn, u32 log_p, u32 padding, u32 lo
   return 0;
 }
 void emu_set_wide_key_ring(int on) { g_wide_key_ring = on != 0; }
+// the GLWE dimension of the keys emu_bsk_prepare lays out from here on (0: every field's natural layout)
+void emu_set_key_k(int k) { g_key_k = k; }
+// the pair kernel: the complex transform, N = 512, k = 1
+int emu_blind_rotate_pair(u32 n, u32 log_p, u32 padding, u32 log_base, u32 levels, size_t batch, const u32* lwe, const u32* tv,
+                          size_t tv_stride, const void* bsk, u32* out_glwe, u32* out_lwe) {
+  PbsParams P = make_params(n, 1, 9, log_p, padding, log_base, levels);
+  blind_rotate_pair_emu<FftField, 9>(P, batch, lwe, tv, tv_stride, (const FftField::elem*)bsk, out_glwe, out_lwe);
+  return 0;
+}
 
 int emu_external_product(int field, int g, u32 k, u32 logn, u32 log_base, u32 levels, const void* ggsw,
                          const u32* glwe, u32* out) {

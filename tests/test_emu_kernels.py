@@ -231,7 +231,11 @@ def prepared(emu, field, params, bsk, g=1):
     flat = np.ascontiguousarray(bsk, dtype=np.uint32).reshape(-1, params.N)
     parts = emu.emu_field_parts(field)
     out = np.zeros((flat.shape[0], parts, params.N), dtype=np.uint64)
-    assert emu.emu_bsk_prepare(field, params.glwe_poly_degree, g, C.c_size_t(flat.shape[0]), p32(flat), p64(out)) == 0
+    emu.emu_set_key_k(params.k)   # the key's layout depends on (field, N, k): pbs_wave.h::key_layout_e
+    try:
+        assert emu.emu_bsk_prepare(field, params.glwe_poly_degree, g, C.c_size_t(flat.shape[0]), p32(flat), p64(out)) == 0
+    finally:
+        emu.emu_set_key_k(0)
     return out
 
 
@@ -473,6 +477,41 @@ def test_wide_team_blind_rotation_vs_oracle(emu, oracle, k, logn, n, pbs, log_p,
     finally:
         emu.emu_set_segments(1)
         emu.emu_set_wide_key_ring(1)
+    assert rc == 0
+    for b in range(batch):
+        _, tr = oracle.bootstrap(params, lwe[b], bsk, ksk, tvs[b], trace=True)
+        assert np.array_equal(glwe[b], tr["acc_final"]), f"sample {b}"
+        assert np.array_equal(ext[b], tr["extracted_lwe"]), f"sample {b}"
+
+
+@pytest.mark.parametrize("n,pbs,log_p,segments", [(5, (8, 2), 2, 1), (4, (8, 2), 2, 2), (3, (4, 6), 2, 1), (3, (13, 2), 2, 1), (3, (9, 1), 2, 1),
+                                                  (3, (5, 5), 4, 3)])
+def test_pair_kernel_blind_rotation_vs_oracle(emu, oracle, n, pbs, log_p, segments):
+    """pbs_wave.h::blind_rotate_pair -- ONE wave per sample at N = 512, k = 1: polynomial c in lanes 32 c .. 32 c + 31, 8
+    transform elements per lane (NttShape<8, 0>: three passes, two transposes serving both polynomials), spectra handed
+    between the halves through LDS under a wave-level fence, no barrier.  Same words as the reference's loop: cfg1's shape,
+    six levels, the rounding bound's admission edge (log2 B = 13), one level, five levels; a~ = 0 and b~ -> 2N rows, per-sample
+    test vectors, segmented rotations."""
+    k, logn = 1, 9
+    if not field_exact(FFT, k, logn, pbs):
+        pytest.skip("outside the rounding bound")
+    params = oracle.Params(k, logn, n, oracle.Decomposer(*pbs), log_p=log_p)
+    batch = 3
+    lwe, bsk, ksk, _ = oracle.synthetic_inputs(params, batch, cfg_index=160 + n)
+    rng = np.random.default_rng(n * 11 + pbs[0])
+    tvs = rng.integers(0, 1 << log_p, size=(batch, params.N)).astype(np.uint32)
+    lwe = lwe.copy()
+    lwe[0, 0] = 0
+    lwe[1, n] = 0xFFFFFFFF
+    spec = prepared(emu, FFT, params, bsk, 1)
+    glwe = np.zeros((batch, k + 1, params.N), dtype=np.uint32)
+    ext = np.zeros((batch, params.big_n + 1), dtype=np.uint32)
+    emu.emu_set_segments(segments)
+    try:
+        rc = emu.emu_blind_rotate_pair(n, log_p, 1, pbs[0], pbs[1], C.c_size_t(batch), p32(lwe), p32(tvs), C.c_size_t(params.N),
+                                       p64(spec), p32(glwe), p32(ext))
+    finally:
+        emu.emu_set_segments(1)
     assert rc == 0
     for b in range(batch):
         _, tr = oracle.bootstrap(params, lwe[b], bsk, ksk, tvs[b], trace=True)

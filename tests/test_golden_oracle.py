@@ -101,7 +101,11 @@ def test_device_headers_reproduce_the_fixtures(emu, name):
         flat = np.ascontiguousarray(a["bsk"]).reshape(-1, 1 << logn)
         parts = emu.emu_field_parts(field)
         spec = np.zeros((flat.shape[0], parts, 1 << logn), dtype=np.uint64)
-        assert emu.emu_bsk_prepare(field, logn, 1, C.c_size_t(flat.shape[0]), tek.p32(flat), tek.p64(spec)) == 0
+        emu.emu_set_key_k(k)   # the key's layout depends on (field, N, k)
+        try:
+            assert emu.emu_bsk_prepare(field, logn, 1, C.c_size_t(flat.shape[0]), tek.p32(flat), tek.p64(spec)) == 0
+        finally:
+            emu.emu_set_key_k(0)
         glwe = np.zeros((rows, k + 1, 1 << logn), dtype=np.uint32)
         ext = np.zeros((rows, k * (1 << logn) + 1), dtype=np.uint32)
         lwe = np.ascontiguousarray(a["lwe_in"][:rows])

@@ -436,7 +436,8 @@ class Context:
                 "waves_per_team": waves.value, "samples_per_team": per_team.value,
                 "kernel": "wide team (2 waves per polynomial: split by level and key part)"
                           if waves.value == 2 * k1 and per_team.value == 1 and segments.value == 1 and self.backend == "fp64-fft"
-                          and self.params.glwe_poly_degree <= 10 else "team"}
+                          and self.params.glwe_poly_degree <= 10
+                          else "pair (one wave per sample, both polynomials side by side)" if waves.value == 1 else "team"}
 
     def last_kernel_ms(self):
         br, ks = C.c_float(), C.c_float()

@@ -693,7 +693,7 @@ static int load_key_common(tfhe_context* ctx, const u32* d_bsk_raw, const u32* d
   }
   if (!ctx->d_ksk)
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_ksk), ksk_words * sizeof(u32)));
-  HIP_TRY(ctx, launch::bsk_prepare(ctx->stream, ctx->field, ctx->pbs.log_n, ctx->d_tw, d_bsk_raw, bsk_polys, ctx->d_bsk));
+  HIP_TRY(ctx, launch::bsk_prepare(ctx->stream, ctx->field, ctx->pbs.log_n, ctx->pbs.k, ctx->d_tw, d_bsk_raw, bsk_polys, ctx->d_bsk));
   if (ksk_needs_copy)
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_ksk, d_ksk_raw, ksk_words * sizeof(u32),
                                 hipMemcpyDeviceToDevice, ctx->stream));
@@ -872,7 +872,7 @@ int tfhe_prepare_ggsw_device(tfhe_context* ctx, const uint32_t* ggsw, size_t ggs
   if (st) return st;
   if (!ggsw || !ggsw_prepared || ggsw_count == 0) return fail(ctx, TFHE_ERR_INVALID_ARGUMENT, "null pointer / zero count");
   const size_t polys = ggsw_count * ctx->R * (ctx->params.glwe_dimension + 1);
-  HIP_TRY(ctx, launch::bsk_prepare(ctx->stream, ctx->field, ctx->pbs.log_n, ctx->d_tw, ggsw, polys, ggsw_prepared));
+  HIP_TRY(ctx, launch::bsk_prepare(ctx->stream, ctx->field, ctx->pbs.log_n, ctx->pbs.k, ctx->d_tw, ggsw, polys, ggsw_prepared));
   return TFHE_OK;
 }
 

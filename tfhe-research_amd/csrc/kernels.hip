@@ -240,7 +240,7 @@ __global__ void __launch_bounds__(256) bsk_prepare_kernel(const typename F::elem
                                                          const u32* __restrict__ polys,
                                                          size_t poly_count,
                                                          typename F::elem* __restrict__ spectra,
-                                                         typename F::elem n_inv) {
+                                                         typename F::elem n_inv, int layout_e) {
   typedef typename F::elem elem;
   constexpr int N = 1 << LOGN;
   constexpr int G = GroupOf<F, LOGN>::value;
@@ -266,6 +266,13 @@ __global__ void __launch_bounds__(256) bsk_prepare_kernel(const typename F::elem
   w.twg_ = tw;
   w.scratch_ = reinterpret_cast<elem*>(g_smem + twiddle_bytes<F, LOGN>() + (size_t)group * N * 8);
   w.acc_ = nullptr;
+  // the key's layout (pbs_wave.h::key_layout_e): the pair kernel's at N = 512, k = 1 in the complex transform
+  if constexpr (key_layout_e<F, LOGN, 1>() != 0) {
+    if (layout_e == key_layout_e<F, LOGN, 1>()) {
+      bsk_prepare_wave<F, LOGN, G, key_layout_e<F, LOGN, 1>()>(w, polys + poly * N, spectra + poly * (N >> F::kLogShrink) * F::kParts, n_inv);
+      return;
+    }
+  }
   bsk_prepare_wave<F, LOGN, G>(w, polys + poly * N, spectra + poly * (N >> F::kLogShrink) * F::kParts, n_inv);
 }
 
@@ -340,6 +347,132 @@ blind_rotate_kernel(PbsParams P, const typename F::elem* __restrict__ tw,
     if (lwe_extracted) sample_extract_team<LOGN, K, G>(w, lwe_extracted + sample[s] * ((size_t)K * N + 1), s);
   }
 }
+
+// ------------------------------------------------------------------------------ blind rotation, pair kernel
+// ONE wavefront per sample at k = 1, N = 512 in the complex transform (pbs_wave.h::blind_rotate_pair): polynomial c in lanes
+// 32 c .. 32 c + 31, 8 elements per lane, no workgroup barrier.  The shape's throughput kernel (the launch plan -- key
+// slices, two streams -- is the team kernel's: launch_blind_rotate); same arguments as blind_rotate_kernel.
+// LDS: [ twiddles ][ half 0: buffer N x 4 B... | half 1 ] = 4 KiB + 2 x 4 KiB buffers + 2 x 2 KiB accumulator polynomials.
+template <class F, int LOGN, int K>
+constexpr bool pair_shape() {
+  return F::kLogShrink == 1 && F::kParts == 2 && LOGN == 9 && K == 1;
+}
+template <class Elem>
+struct PairWave {
+  unsigned char* buffers_;  // half 0's transpose / exchange buffer; half 1's follows
+  u32* accs_;               // accumulator polynomial 0; polynomial 1 follows
+  const Elem* tw_;
+  const Elem* twg_;
+  unsigned buffer_bytes_, acc_words_;
+  __device__ __forceinline__ int tid() const { return (int)(threadIdx.x & 31u); }
+  __device__ __forceinline__ int group() const { return (int)((threadIdx.x >> 5) & 1u); }
+  __device__ __forceinline__ void wave_sync() const {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  __device__ __forceinline__ void poly_sync() const { wave_sync(); }
+  __device__ __forceinline__ void team_sync() const { wave_sync(); }  // the team is this wave
+  __device__ __forceinline__ Elem* scratch() const { return reinterpret_cast<Elem*>(buffers_ + (size_t)group() * buffer_bytes_); }
+  __device__ __forceinline__ const Elem* scratch_of(int half) const { return reinterpret_cast<const Elem*>(buffers_ + (size_t)half * buffer_bytes_); }
+  __device__ __forceinline__ u32* acc(int = 0) const { return accs_ + (size_t)group() * acc_words_; }
+  __device__ __forceinline__ const Elem* twiddles() const { return tw_; }
+  __device__ __forceinline__ const Elem* twiddles_uniform() const { return twg_; }
+  __device__ __forceinline__ u32 uniform(u32 v) const { return __builtin_amdgcn_readfirstlane(v); }
+  __device__ __forceinline__ void lds_add(u32* p, u32 v) const {
+    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  __device__ __forceinline__ void compiler_fence() const { asm volatile("" ::: "memory"); }
+};
+
+template <class F, int LOGN>
+struct PairCfg {
+  static constexpr int N = 1 << LOGN;
+  static constexpr int kThreads = 64;
+  static constexpr size_t kTwBytes = (size_t)staged_twiddle_words<F, LOGN>() * sizeof(typename F::elem);
+  static constexpr unsigned kBufferBytes = (unsigned)N * 8u;
+  static constexpr size_t kLds = kTwBytes + 2 * (size_t)kBufferBytes + 2 * (size_t)N * 4;
+};
+
+#ifndef TFHE_PAIR_MIN_WAVES
+#define TFHE_PAIR_MIN_WAVES 2
+#endif
+template <class F, int LOGN>
+__global__ void __launch_bounds__(64, TFHE_PAIR_MIN_WAVES)
+blind_rotate_pair_kernel(PbsParams P, const typename F::elem* __restrict__ tw, const u32* __restrict__ lwe_in, size_t batch,
+                         const u32* __restrict__ tv, size_t tv_stride, const typename F::elem* __restrict__ bsk,
+                         u32* glwe_out, u32* __restrict__ lwe_extracted, u32 i_begin, u32 i_end, u32* glwe_state) {
+  typedef typename F::elem elem;
+  using C = PairCfg<F, LOGN>;
+  constexpr int N = C::N;
+  constexpr int T = 32;
+  constexpr int EC = N / T;
+  constexpr int K = 1;
+  elem* twl = reinterpret_cast<elem*>(g_smem);
+  ntt_stage_twiddles<LOGN - F::kLogShrink, 0, elem, staged_twiddle_words<F, LOGN>()>(twl, tw, (int)threadIdx.x, 64);
+  __syncthreads();
+  PairWave<elem> w;
+  w.buffers_ = g_smem + C::kTwBytes;
+  w.buffer_bytes_ = C::kBufferBytes;
+  w.accs_ = reinterpret_cast<u32*>(w.buffers_ + 2 * (size_t)C::kBufferBytes);
+  w.acc_words_ = (unsigned)N;
+  w.tw_ = twl;
+  w.twg_ = tw;
+  const size_t sample = blockIdx.x;  // grid = batch
+  (void)batch;
+  const u32* resume = i_begin > 0 ? glwe_state + sample * (size_t)(K + 1) * N : nullptr;
+  blind_rotate_pair<F, LOGN>(w, P, lwe_in + sample * (P.n + 1), tv + sample * tv_stride, bsk, i_begin, i_end, resume);
+  const int tid = w.tid(), me = w.group();
+  const u32* acc = w.acc();
+  if (i_end < P.n) {  // not the last segment: park the accumulators
+    u32* dst = glwe_state + (sample * (size_t)(K + 1) + me) * N;
+#pragma unroll
+    for (int r = 0; r < EC; ++r) dst[r * T + tid] = acc[r * T + tid];
+    return;
+  }
+  if (glwe_out) {
+    u32* dst = glwe_out + (sample * (size_t)(K + 1) + me) * N;
+#pragma unroll
+    for (int r = 0; r < EC; ++r) dst[r * T + tid] = acc[r * T + tid];
+  }
+  if (lwe_extracted) {  // sample_extract at index 0 (bootstrapping.rs:122-156)
+    u32* out = lwe_extracted + sample * ((size_t)K * N + 1);
+    if (me < K) {
+#pragma unroll
+      for (int r = 0; r < EC; ++r) {
+        const int x = r * T + tid;
+        out[me * N + x] = (x == 0) ? acc[0] : (0u - acc[N - x]);
+      }
+    } else if (tid == 0) {
+      out[K * N] = acc[0];
+    }
+  }
+}
+
+// The kernel that rotates a shape's large batches, with what the launcher needs to know about it
+template <class F, int LOGN, int K>
+struct RotateKernel {
+  using C = TeamCfg<F, LOGN, K>;
+  static constexpr int kThreads = C::kThreads;
+  static constexpr size_t kLds = C::kLds;
+  static constexpr int kSamples = C::S;   // samples per workgroup
+  static constexpr int kWaves = C::kWaves;
+  static auto get() { return blind_rotate_kernel<F, LOGN, K>; }
+};
+template <int LOGN, int K>
+struct RotateKernelPair {
+  using C = PairCfg<FftField, LOGN>;
+  static constexpr int kThreads = C::kThreads;
+  static constexpr size_t kLds = C::kLds;
+  static constexpr int kSamples = 1;
+  static constexpr int kWaves = 1;
+  static auto get() { return blind_rotate_pair_kernel<FftField, LOGN>; }
+};
+#ifndef TFHE_PAIR_KERNEL
+#define TFHE_PAIR_KERNEL 1  // 0: A/B builds that keep the two-wave team at N = 512, k = 1 (the key keeps the pair layout)
+#endif
+template <class F, int LOGN, int K>
+using RotateKernelOf = typename std::conditional<(TFHE_PAIR_KERNEL && pair_shape<F, LOGN, K>()), RotateKernelPair<LOGN, K>, RotateKernel<F, LOGN, K>>::type;
 
 // ------------------------------------------------------------------------------ blind rotation, wide team
 // The latency shape (pbs_wave.h::blind_rotate_team_wide): 2 (K+1) waves per sample -- wave (c, q) transforms half of
@@ -986,14 +1119,14 @@ inline int current_device_slot() {
 }
 template <class F, int LOGN, int K>
 hipError_t resident_teams(unsigned* out) {
-  using C = TeamCfg<F, LOGN, K>;
+  using RK = RotateKernelOf<F, LOGN, K>;
   static std::atomic<unsigned> cached[kMaxDevices];
   const int dev = current_device_slot();
   unsigned capacity = cached[dev].load(std::memory_order_acquire);
   if (capacity == 0) {
-    auto kern = blind_rotate_kernel<F, LOGN, K>;
+    auto kern = RK::get();
     int per_cu = 0, cus = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, C::kThreads, C::kLds);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, RK::kThreads, RK::kLds);
     if (e != hipSuccess) return e;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
     capacity = (unsigned)(per_cu > 0 ? per_cu : 1) * (unsigned)(cus > 0 ? cus : 256);
@@ -1072,19 +1205,20 @@ hipError_t plan_blind_rotate(const PbsParams& P, size_t batch, bool can_park, bo
     return hipErrorInvalidValue;
   } else {
     using C = TeamCfg<F, LOGN, K>;
+    using RK = RotateKernelOf<F, LOGN, K>;
     static std::atomic<unsigned long long> lds_done{0};
-    hipError_t e = allow_lds(blind_rotate_kernel<F, LOGN, K>, C::kLds, lds_done);
+    hipError_t e = allow_lds(RK::get(), RK::kLds, lds_done);
     unsigned capacity = 0;
     if (e == hipSuccess) e = resident_teams<F, LOGN, K>(&capacity);
     if (e != hipSuccess) return e;
     const size_t key_bytes = (size_t)P.n * (K + 1) * P.levels * (K + 1) * F::kParts * C::N * 8;
-    const BlindRotatePlan plan = blind_rotate_plan<F>(batch, can_park, have_side, P.n, key_bytes, (u32)LOGN, (size_t)capacity * C::S);
+    const BlindRotatePlan plan = blind_rotate_plan<F>(batch, can_park, have_side, P.n, key_bytes, (u32)LOGN, (size_t)capacity * RK::kSamples);
     out->chunk = plan.chunk;
     out->segments = plan.segments;
     out->streams = plan.streams == 2 && plan.segments > 1 ? 2 : 1;
-    out->resident_samples = (size_t)capacity * C::S;
-    out->samples_per_team = C::S;
-    out->waves_per_sample = C::kWaves;
+    out->resident_samples = (size_t)capacity * RK::kSamples;
+    out->samples_per_team = RK::kSamples;
+    out->waves_per_sample = RK::kWaves;
     if (batch > 0 && batch <= wide_max_batch<F, LOGN, K>(P, shape)) {  // the wide team: one launch over the whole key
       out->chunk = batch;
       out->segments = 1;
@@ -1110,9 +1244,10 @@ hipError_t launch_blind_rotate(hipStream_t s, const PbsParams& P, const void* tw
       if (batch <= wide_max_batch<F, LOGN, K>(P, shape))
         return launch_blind_rotate_wide<F, LOGN, K>(s, P, tw, lwe_in, batch, tv, tv_stride, bsk, glwe_out, lwe_extracted);
     }
-    auto kern = blind_rotate_kernel<F, LOGN, K>;
+    using RK = RotateKernelOf<F, LOGN, K>;
+    auto kern = RK::get();
     static std::atomic<unsigned long long> lds_done{0};
-    hipError_t e = allow_lds(kern, C::kLds, lds_done);
+    hipError_t e = allow_lds(kern, RK::kLds, lds_done);
     if (e != hipSuccess) return e;
     unsigned capacity = 0;
     if ((e = resident_teams<F, LOGN, K>(&capacity)) != hipSuccess) return e;
@@ -1125,7 +1260,7 @@ hipError_t launch_blind_rotate(hipStream_t s, const PbsParams& P, const void* tw
     }
     const size_t key_bytes = (size_t)P.n * (K + 1) * P.levels * (K + 1) * F::kParts * C::N * 8;
     const BlindRotatePlan plan =
-        blind_rotate_plan<F>(batch, state != nullptr, have_side, P.n, key_bytes, (u32)LOGN, (size_t)capacity * C::S);
+        blind_rotate_plan<F>(batch, state != nullptr, have_side, P.n, key_bytes, (u32)LOGN, (size_t)capacity * RK::kSamples);
     const int parts = plan.streams == 2 && plan.segments > 1 ? 2 : 1;
     const u32 per = (P.n + plan.segments - 1) / plan.segments;
     if (parts == 2) {  // fork: the side stream starts after everything already on s
@@ -1135,14 +1270,14 @@ hipError_t launch_blind_rotate(hipStream_t s, const PbsParams& P, const void* tw
     for (size_t off = 0; off < batch; off += plan.chunk) {
       const size_t here = batch - off < plan.chunk ? batch - off : plan.chunk;
       // part q = samples [q * share, (q + 1) * share) of the chunk; share is a multiple of the samples per team
-      const size_t share = (((here + parts - 1) / parts + C::S - 1) / C::S) * C::S;
+      const size_t share = (((here + parts - 1) / parts + RK::kSamples - 1) / RK::kSamples) * RK::kSamples;
       for (u32 i0 = 0; i0 < P.n; i0 += per) {
         const u32 i1 = i0 + per < P.n ? i0 + per : P.n;
         for (int q = 0; q < parts; ++q) {
           if ((size_t)q * share >= here) break;
           const size_t o = off + (size_t)q * share;
           const size_t cnt = here - (size_t)q * share < share ? here - (size_t)q * share : share;
-          hipLaunchKernelGGL(kern, dim3((unsigned)((cnt + C::S - 1) / C::S)), dim3(C::kThreads), C::kLds,
+          hipLaunchKernelGGL(kern, dim3((unsigned)((cnt + RK::kSamples - 1) / RK::kSamples)), dim3(RK::kThreads), RK::kLds,
                              q ? side->stream : s, P, tw, lwe_in + o * ((size_t)P.n + 1), cnt, tv + o * tv_stride,
                              tv_stride, bsk, glwe_out ? glwe_out + o * (size_t)(K + 1) * C::N : nullptr,
                              lwe_extracted ? lwe_extracted + o * ((size_t)K * C::N + 1) : nullptr, i0, i1,
@@ -1229,7 +1364,7 @@ hipError_t launch_external_product(hipStream_t s, const PbsParams& P, const void
 
 template <class F, int LOGN>
 hipError_t launch_bsk_prepare(hipStream_t s, const void* tw_v, const u32* polys, size_t poly_count,
-                              void* spectra_v) {
+                              void* spectra_v, u32 k) {
   if constexpr (!field_shape_ok<F, LOGN>()) {
     return hipErrorInvalidValue;
   } else {
@@ -1244,8 +1379,9 @@ hipError_t launch_bsk_prepare(hipStream_t s, const void* tw_v, const u32* polys,
     hipError_t e = allow_lds(kern, lds, lds_done);
     if (e != hipSuccess) return e;
     const unsigned grid = (unsigned)((poly_count + groups - 1) / groups);
+    const int layout_e = k == 1 ? key_layout_e<F, LOGN, 1>() : k == 2 ? key_layout_e<F, LOGN, 2>() : 0;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, tw, polys, poly_count, spectra,
-                       F::n_inv(LOGN - F::kLogShrink));
+                       F::n_inv(LOGN - F::kLogShrink), layout_e);
     return hipGetLastError();
   }
 }
@@ -1387,9 +1523,9 @@ int samples_per_team(int field, u32 log_n, u32 k) {
   } while (0)
 #endif
 
-hipError_t bsk_prepare(hipStream_t s, int field, u32 log_n, const void* tw, const u32* polys,
+hipError_t bsk_prepare(hipStream_t s, int field, u32 log_n, u32 k, const void* tw, const u32* polys,
                        size_t poly_count, void* spectra) {
-  TFHE_DISPATCH_FIELD(field, TFHE_DISPATCH_LOGN(log_n, (launch_bsk_prepare<FF, LL>(s, tw, polys, poly_count, spectra))));
+  TFHE_DISPATCH_FIELD(field, TFHE_DISPATCH_LOGN(log_n, (launch_bsk_prepare<FF, LL>(s, tw, polys, poly_count, spectra, k))));
 }
 
 hipError_t blind_rotate(hipStream_t s, int field, const PbsParams& P, const void* tw,

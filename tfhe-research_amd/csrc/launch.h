@@ -24,8 +24,9 @@ bool field_shape_supported(int field, u32 log_n);
 int samples_per_team(int field, u32 log_n, u32 k);
 
 // twiddle table psi_rev[N] (8-byte field elements) must already be on the device;
-// spectra: poly_count x field_parts x N elements
-hipError_t bsk_prepare(hipStream_t s, int field, u32 log_n, const void* tw, const u32* polys,
+// spectra: poly_count x field_parts x N elements; k (the GLWE dimension) selects the key's layout with log_n and the
+// field (pbs_wave.h::key_layout_e: the pair kernel's at N = 512, k = 1 in the complex transform)
+hipError_t bsk_prepare(hipStream_t s, int field, u32 log_n, u32 k, const void* tw, const u32* polys,
                        size_t poly_count, void* spectra);
 
 // A second stream of the caller's, with the two events that fork it from and join it to the main one: batches larger than

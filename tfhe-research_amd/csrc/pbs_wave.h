@@ -35,6 +35,15 @@ TFHE_HD void static_for(F&& f) {
   }
 }
 
+// Shape the prepared bootstrapping key of a parameter set is laid out for (wave_ntt.h::spectrum_slot, LAYOUT_E): 0 = the
+// team kernel's own shape.  N = 512 with k = 1 in the complex transform: the PAIR kernel's (both polynomials of a sample in
+// one wavefront, 32 lanes x 8 elements each) -- it is that shape's throughput kernel; the team / wide / standalone
+// external-product kernels of the shape read the same key through the same slot formula.
+template <class F, int LOGN, int K>
+constexpr int key_layout_e() {
+  return (F::kLogShrink == 1 && LOGN == 9 && K == 1) ? 8 : 0;
+}
+
 // Plain-old-data view of the parameter set the kernels need (derived once on the host).
 struct PbsParams {
   u32 n;            // LWE dimension
@@ -300,7 +309,7 @@ TFHE_HD void external_product_team_multi(const Ctx& c, const PbsParams& P, const
     const elem* tile = tile_ptr(level, source_of(src_poly), q);
 #pragma unroll
     for (int r = 0; r < CH; ++r)
-      kbuf[buf][r] = tile[TFHE_PROBE_HOT_KEY ? (lane & 63) + r : spectrum_slot<LT, G, (int)sizeof(elem)>(lane, r0 + r)];
+      kbuf[buf][r] = tile[TFHE_PROBE_HOT_KEY ? (lane & 63) + r : spectrum_slot<LT, G, (int)sizeof(elem), key_layout_e<F, LOGN, K>()>(lane, r0 + r)];
   };
   // the contexts of the samples' buffers (NS == 1: the level's parity buffer, see above)
   auto buffers_of_level = [&](u32 t, Ctx (&cl)[NS]) {
@@ -666,7 +675,8 @@ struct WideKeyRing {
     constexpr int level = M / (K + 1), sp = M % (K + 1);
     const typename F::elem* tile = ggsw + ((((size_t)sp * LEVELS + level) * (K + 1) + me) * 2 + q) * ((size_t)1 << (LOGN - 1));
 #pragma unroll
-    for (int r = 0; r < E; ++r) slot[M % RING][r] = tile[spectrum_slot<LOGN - 1, 1, (int)sizeof(typename F::elem)>(lane, r)];
+    for (int r = 0; r < E; ++r)
+      slot[M % RING][r] = tile[spectrum_slot<LOGN - 1, 1, (int)sizeof(typename F::elem), key_layout_e<F, LOGN, K>()>(lane, r)];
   }
   // before the first product: rows 0 .. RING-1
   TFHE_HD void prime(const typename F::elem* ggsw, int me, int q, int lane) {
@@ -730,7 +740,8 @@ TFHE_HD void external_product_team_wide(const Ctx& c, const PbsParams& P, const 
     constexpr int sp = ci / PIECES, r0 = (ci % PIECES) * CH;
     const elem* tile = ggsw + ((((size_t)sp * levels + level) * (K + 1) + me) * 2 + q) * N;
 #pragma unroll
-    for (int r = 0; r < CH; ++r) kbuf[RINGED ? 0 : buf][RINGED ? 0 : r] = tile[spectrum_slot<LT, 1, (int)sizeof(elem)>(lane, r0 + r)];
+    for (int r = 0; r < CH; ++r)
+      kbuf[RINGED ? 0 : buf][RINGED ? 0 : r] = tile[spectrum_slot<LT, 1, (int)sizeof(elem), key_layout_e<F, LOGN, K>()>(lane, r0 + r)];
   };
   if constexpr (!RINGED) {
     load_chunk(0u, IntC<0>{}, 0);  // in flight under the forward transforms
@@ -875,6 +886,171 @@ TFHE_HD void blind_rotate_team_wide(const Ctx& c, const PbsParams& P, const u32*
 }
 
 // ---------------------------------------------------------------------------------------------
+// The PAIR kernel: ONE wavefront per LWE sample at k = 1, N = 512.
+//
+// A team of two waves at N = 512 holds 4 transform elements per lane: four register passes and three transposes per
+// transform, two team barriers per level, and a CU holds 6 samples (3 waves per SIMD).  Here both polynomials of a sample sit
+// side by side in ONE wave -- polynomial c in lanes 32 c .. 32 c + 31, 8 elements per lane (NttShape<LT, 0>) -- and the same
+// instruction stream transforms both: three register passes, TWO transposes per transform that serve both polynomials, the
+// two digit spectra change halves through the wave's own LDS buffers under a wave-level fence, and there is NO workgroup
+// barrier anywhere (one wave's LDS operations execute in order).  A third fewer LDS cycles per sample, and 8 samples per CU
+// (2 waves per SIMD at the N = 1024 kernel's register footprint) instead of 6.
+//   half c: decomposes polynomial c, forward-transforms its `levels` digit rows, accumulates BOTH key parts of output
+//   column c over both polynomials' spectra (its own from registers, the other half's read back from LDS), inverse-transforms
+//   its two accumulators (one after the other's transposes: ntt_inverse_pair) and updates accumulator polynomial c.
+// Ctx: tid() = lane within the half (0..31), group() = half = polynomial, scratch() / scratch_of(c) = a half's buffer.
+// ---------------------------------------------------------------------------------------------
+template <class F, int LOGN, class Ctx, class Src, class Out>
+TFHE_HD void external_product_pair(const Ctx& c, const PbsParams& P, const typename F::elem* ggsw, Src src, Out out) {
+  typedef typename F::elem elem;
+  static_assert(F::kParts == 2 && F::kLogShrink == 1 && F::kCoeffs == 2, "the complex transform: two key parts, two coefficients per element");
+  constexpr int K = 1;
+  constexpr int LT = LOGN - 1;
+  constexpr int G = 0;  // half a wave per polynomial
+  constexpr int E = NttShape<LT, G>::kE;
+  constexpr int EC = 2 * E;
+  constexpr int T = NttShape<LT, G>::kThreads;  // 32
+  constexpr int N = 1 << LT;
+  const int tid = c.tid();
+  const int me = c.group();
+
+  elem accum[2][E];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int r = 0; r < E; ++r) accum[q][r] = F::zero();
+
+  TopConsts<F, LT, G, true> ftop;
+  ftop.issue(c.twiddles_uniform());
+  u32 v[EC];
+  const RoundConsts rc = round_consts(P.ignored_bits);
+#pragma unroll
+  for (int r = 0; r < EC; ++r) v[r] = round_value_fast(src(r * T + tid), rc);
+  ftop.ready();
+
+  // key chunks of a level for my column: source polynomial (mine first, then the other half's), piece of the spectrum, key
+  // part; CH elements at a time, double-buffered in registers
+  constexpr int CH = 4;
+  constexpr int PIECES = E / CH;
+  constexpr int CHUNKS = 2 * PIECES * 2;  // per level
+  elem kbuf[2][CH];
+  auto load_chunk = [&](u32 level, auto ci_c, int buf) {
+    constexpr int ci = decltype(ci_c)::value;
+    constexpr int q = ci % 2, r0 = ((ci / 2) % PIECES) * CH, other = ci / (2 * PIECES);
+    const int sp = other ? 1 - me : me;
+    const elem* tile = ggsw + ((((size_t)sp * P.levels + level) * (K + 1) + me) * 2 + q) * N;
+#pragma unroll
+    for (int r = 0; r < CH; ++r) kbuf[buf][r] = tile[spectrum_slot<LT, G, (int)sizeof(elem)>(tid, r0 + r)];
+  };
+#pragma unroll 1
+  for (u32 t = 0; t < P.levels; ++t) {
+    const u32 level = P.levels - 1 - t;
+    const u32 shift = P.first_shift + P.log_base * t;
+    const u32 carry_width = (t == 0) ? 0u : 1u;
+    load_chunk(level, IntC<0>{}, 0);  // in flight under the forward transform
+    c.compiler_fence();
+    elem work[E];
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+      u32 dg[2];
+      dg[0] = decompose_limb_fast<true>(v[r], shift, P.log_base, carry_width);
+      dg[1] = decompose_limb_fast<true>(v[r + E], shift, P.log_base, carry_width);
+      work[r] = F::from_digits(dg);
+    }
+    ntt_forward<F, LT, G, true, true>(c, work, ftop);
+    // hand my spectrum to the other half: through my buffer (free between two transforms)
+    elem* mine = c.scratch();
+#pragma unroll
+    for (int r = 0; r < E; ++r) mine[exchange_slot<LT, G>(tid, r)] = work[r];
+    c.wave_sync();
+    elem d[CH];
+    static_for<0, CHUNKS>([&](auto ci_c) {
+      constexpr int ci = decltype(ci_c)::value;
+      constexpr int q = ci % 2, r0 = ((ci / 2) % PIECES) * CH, other = ci / (2 * PIECES);
+      if constexpr (ci + 1 < CHUNKS) load_chunk(level, IntC<ci + 1>{}, (ci + 1) % 2);
+      if constexpr (q == 0) {
+        if constexpr (other == 0) {
+#pragma unroll
+          for (int r = 0; r < CH; ++r) d[r] = work[r0 + r];
+        } else {
+          const elem* spec = c.scratch_of(1 - me);
+#pragma unroll
+          for (int r = 0; r < CH; ++r) d[r] = spec[exchange_slot<LT, G>(tid, r0 + r)];
+        }
+      }
+      c.compiler_fence();  // keep the next chunk's loads above this chunk's arithmetic
+#pragma unroll
+      for (int r = 0; r < CH; ++r) accum[q][r0 + r] = F::mul_add(d[r], kbuf[ci % 2][r], accum[q][r0 + r]);
+    });
+    c.wave_sync();  // the other half has read my spectrum before the next transform's transposes overwrite it
+  }
+
+  TopConsts<F, LT, G, false> itop;
+  itop.issue(c.twiddles_uniform());
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    accum[0][r] = F::before_inverse(accum[0][r]);
+    accum[1][r] = F::before_inverse(accum[1][r]);
+  }
+  itop.ready();
+  ntt_inverse_pair<F, LT, G>(c, accum[0], accum[1], itop);
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    elem parts[2] = {accum[0][r], accum[1][r]};
+    u32 vals[2];
+    F::finish(parts, vals);
+    out(r * T + tid, vals[0]);
+    out((r + E) * T + tid, vals[1]);
+  }
+}
+
+// Blind rotation of ONE sample by one wave (bootstrapping.rs:67-105); segments as blind_rotate_team_multi.
+template <class F, int LOGN, class Ctx>
+TFHE_HD void blind_rotate_pair(const Ctx& c, const PbsParams& P, const u32* lwe /* n+1 */, const u32* tv /* N, un-encoded */,
+                               const typename F::elem* bsk /* prepared, pair layout */, u32 i_begin, u32 i_end,
+                               const u32* resume /* [2][N], read if i_begin > 0 */) {
+  constexpr int N = 1 << LOGN;
+  constexpr int T = 32;
+  constexpr int EC = N / T;  // accumulator words per lane
+  constexpr int K = 1;
+  const int tid = c.tid();
+  const int me = c.group();
+  u32* acc = c.acc();
+  if (i_begin > 0) {
+    const u32* from = resume + (size_t)me * N;
+#pragma unroll
+    for (int r = 0; r < EC; ++r) acc[r * T + tid] = from[r * T + tid];
+  } else {
+    // acc = X^{-b~} * (0, tv << tv_shift)
+    const u32 b_tilde = switch_modulus_2n(lwe[P.n], LOGN);
+    const u32 m = (2u * N - b_tilde) & (2u * N - 1u);
+    const int deg = (int)(m & (N - 1));
+    const u32 flip = (m >> LOGN) & 1u;
+#pragma unroll
+    for (int r = 0; r < EC; ++r) {
+      const int j = r * T + tid;
+      u32 val = 0;
+      if (me == K) {
+        const u32 t = tv[(j - deg) & (N - 1)] << P.tv_shift;
+        val = (flip ^ (u32)(j < deg)) ? (0u - t) : t;
+      }
+      acc[j] = val;
+    }
+  }
+  c.wave_sync();
+  const size_t ggsw_words = (size_t)(K + 1) * P.levels * (K + 1) * 2 * (N >> 1);  // elements
+#pragma unroll 1
+  for (u32 i = i_begin; i < i_end; ++i) {
+    const u32 a_tilde = c.uniform(switch_modulus_2n(lwe[i], LOGN));
+    auto src = [&](int j) -> u32 { return monomial_coeff<LOGN>(acc, j, a_tilde) - acc[j]; };
+    // each half reads and updates only its own polynomial, the rotated reads all happen before the first update
+    auto out = [&](int j, u32 value) { c.lds_add(acc + j, value); };
+    external_product_pair<F, LOGN>(c, P, bsk + (size_t)i * ggsw_words, src, out);
+    c.wave_sync();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Unrolled blind rotation (notes/BMMP Bootstrapping.md:13-25): two key bits per step.  With
 //   X^{a s + a' s'} = s s' (X^{a+a'} - 1) + s (1 - s') (X^a - 1) + (1 - s) s' (X^{a'} - 1) + 1
 // one step is   acc += sum_{m<3} (X^{e_m} - 1) * (BK_{3j+m} [x] acc)   with e = (a+a', a, a') and the
@@ -963,7 +1139,8 @@ TFHE_HD void sample_extract_team(const Ctx& c, u32* out /* K*N + 1 */, int s = 0
 
 // Forward NTT of one u32 polynomial of the bootstrapping key into the prepared layout,
 // pre-scaled by N^-1.
-template <class F, int LOGN, int G, class Ctx>
+// LAYOUT_E: the shape the key is laid out for (key_layout_e; 0: this transform's own)
+template <class F, int LOGN, int G, int LAYOUT_E = 0, class Ctx>
 TFHE_HD void bsk_prepare_wave(const Ctx& c, const u32* poly, typename F::elem* spec /* [kParts][N >> kLogShrink] */,
                               typename F::elem n_inv) {
   typedef typename F::elem elem;
@@ -985,7 +1162,7 @@ TFHE_HD void bsk_prepare_wave(const Ctx& c, const u32* poly, typename F::elem* s
     }
     ntt_forward<F, LT, G>(c, x);
 #pragma unroll
-    for (int r = 0; r < E; ++r) spec[(size_t)part * NS + spectrum_slot<LT, G, (int)sizeof(elem)>(lane, r)] = F::scale_key(x[r], n_inv);
+    for (int r = 0; r < E; ++r) spec[(size_t)part * NS + spectrum_slot<LT, G, (int)sizeof(elem), LAYOUT_E>(lane, r)] = F::scale_key(x[r], n_inv);
   }
 }
 

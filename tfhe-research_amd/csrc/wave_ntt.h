@@ -54,14 +54,16 @@ namespace tfhe {
 // first two stages and the 16 coefficients of the fused third one (F::radix8_small_v)
 constexpr int ntt_twiddle_words(int n) { return n + 18; }
 
+// G = 0: HALF a wave per polynomial (32 lanes): two polynomials side by side in one wavefront, each in its own half --
+// lanes 32 c .. 32 c + 31 hold polynomial c, the same instruction stream transforms both (pbs_wave.h: the pair kernel).
 template <int LOGN, int G = 1>
 struct NttShape {
-  static_assert(G == 1 || G == 2 || G == 4, "waves per polynomial");
+  static_assert(G == 0 || G == 1 || G == 2 || G == 4, "waves per polynomial (0: half a wave)");
   static constexpr int kLogN = LOGN;
   static constexpr int kN = 1 << LOGN;
   static constexpr int kG = G;
-  static constexpr int kThreads = 64 * G;
-  static constexpr int kTBits = (G == 1) ? 6 : (G == 2) ? 7 : 8;
+  static constexpr int kThreads = G == 0 ? 32 : 64 * G;
+  static constexpr int kTBits = (G == 0) ? 5 : (G == 1) ? 6 : (G == 2) ? 7 : 8;
   static constexpr int kEBits = LOGN - kTBits;
   static constexpr int kE = 1 << kEBits;
   static_assert(kEBits >= 2 && kEBits <= 5, "4..32 elements per lane (4: the complex transform at N = 512, four register passes)");
@@ -302,6 +304,11 @@ struct FusedForwardButterfly<F, decltype((void)F::kFusedForwardButterfly)> {
 // ds_read_b64 of both transposes, in both directions, bank-conflict free (tools/ntt_model.py).
 template <int LOGN, int G>
 TFHE_HD int ntt_swizzle(int j) {
+  // 256 16-byte elements over HALF a wave, 8 per lane (the pair kernel at N = 512): linear map of index bits 4..7 into the
+  // 16-byte slot number, found by exhaustive search over such maps under the b128 banking rules restricted to a half's
+  // lane groups: every read and the writes of windows [5,8) and [2,5) conflict free, the writes of window [0,3) 2-way
+  // (16 LDS-array cycles against the ~14 the store's register transfer takes anyway)
+  if (G == 0 && LOGN == 8) return j ^ (((j >> 4) & 1) * 1) ^ (((j >> 5) & 1) * 4) ^ (((j >> 7) & 1) * 10);
   if (G == 1 && LOGN == 10) return j ^ ((j >> 4) & 31);
   // 256 16-byte elements, 4 per lane (the complex transform at N = 512): best linear map of bits 4..7 into the
   // 16-byte slot number under the b128 banking rules -- every read and all but the last window's writes (2-way)
@@ -334,9 +341,19 @@ TFHE_HD int ntt_index(int tid, int r) {
 // global_load_dwordx4 per lane reads 64 x 16 B = 1 KiB contiguous per wave.
 // (16-byte elements -- the complex transform -- are one global_load_dwordx4 each: register r of all
 // threads is contiguous)
-template <int LOGN, int G, int ELEM_BYTES = 8>
+// LAYOUT_E: elements per lane of the shape the key was LAID OUT for.  A prepared key stores spectrum position pos (bit-reversed
+// order; register r of thread tid holds pos = tid E + r at the end of a forward transform) at (pos mod E_l) (n / E_l) +
+// pos / E_l, so that the kernel whose shape has E_l elements per lane reads register r of all its threads contiguously.  A
+// kernel of another shape (E != E_l) reads the same key through the same formula: one context, one prepared key, whatever
+// kernels run on it (pbs_wave.h::KeyLayout picks E_l per parameter set).
+// (LAYOUT_E = 0: the reading kernel's own shape.)
+template <int LOGN, int G, int ELEM_BYTES = 8, int LAYOUT_E = 0>
 TFHE_HD int spectrum_slot(int tid, int r) {
-  if (ELEM_BYTES == 16) return r * NttShape<LOGN, G>::kThreads + tid;
+  if (ELEM_BYTES == 16) {
+    if (LAYOUT_E == 0 || LAYOUT_E == NttShape<LOGN, G>::kE) return r * NttShape<LOGN, G>::kThreads + tid;
+    const int pos = tid * NttShape<LOGN, G>::kE + r;
+    return (pos % LAYOUT_E) * ((1 << LOGN) / LAYOUT_E) + pos / LAYOUT_E;
+  }
   return (r >> 1) * (2 * NttShape<LOGN, G>::kThreads) + tid * 2 + (r & 1);
 }
 
@@ -346,7 +363,8 @@ TFHE_HD int spectrum_slot(int tid, int r) {
 // consecutive 8-byte words per register (conflict-free)
 template <int LOGN, int G>
 TFHE_HD int exchange_slot(int tid, int r) {
-  return (tid >> 6) * (NttShape<LOGN, G>::kN / G) + r * 64 + (tid & 63);
+  if (G == 0) return r * 32 + tid;  // half a wave per polynomial: 32 consecutive 16-byte words per register
+  return (tid >> 6) * (NttShape<LOGN, G>::kN / (G ? G : 1)) + r * 64 + (tid & 63);
 }
 
 // Transpose between two register windows through the group's LDS buffer.
@@ -731,7 +749,7 @@ TFHE_HD void ntt_inverse_pair(const Ctx& c, typename F::elem (&a)[NttShape<LOGN,
                               typename F::elem (&b)[NttShape<LOGN, G>::kE], const Top& top,
                               const Before& before_first_store = Before{}) {
   using S = NttShape<LOGN, G>;
-  static_assert(G == 1 && S::kPasses == 3, "wave-local transposes, three passes");
+  static_assert(G <= 1 && S::kPasses == 3, "wave-local transposes, three passes");
   constexpr bool PRE = PreloadsTwiddles<F>::value;
   LowPassTwiddles<F, LOGN, G, S::kLo3, S::kLo2 - 1, S::kLo3, true, PRE> t3;
   t3.load(c);
