@@ -151,3 +151,39 @@ def test_wide_team_gates_and_graph_capture(oracle):
             gc_.stream.synchronize()
         assert np.array_equal(graphed, team.cpu().numpy())
         ctx.set_stream(None)
+
+
+def test_pair_kernel_takes_over_above_the_team_capacity(oracle):
+    """N = 512, k = 1 (cfg1's shape): batches larger than the chip holds as two-wave teams run the PAIR kernel -- one wave per
+    sample, both polynomials side by side in it (pbs_wave.h::blind_rotate_pair) -- smaller ones the team, the smallest the wide
+    team; all three read ONE prepared key (laid out for the pair kernel) and must return the same words.  1,700 rows through
+    the pair kernel (segmented, two streams) against the same rows in slices of 100 through the team and of 10 through the wide
+    team; rows 0, 1 (b~ -> 2N), 850, 1699 against the oracle; aligned decomposer too."""
+    m = pkg()
+    p = oracle.Params(1, 9, 6, oracle.Decomposer(8, 2), log_p=2)
+    lwe, bsk, ksk, tv = oracle.synthetic_inputs(p, 1700, cfg_index=181)
+    lwe = lwe.copy()
+    lwe[0, 0] = 0
+    lwe[1, p.n] = 0xFFFFFFFF
+    for aligned in (False, True):
+        with m.Context(to_pkg_params(p)) as ctx:
+            ctx.set_decomposer_alignment(aligned)
+            ctx.load_bootstrapping_key(bsk, ksk)
+            big, small, tiny = ctx.blind_rotate_plan(1700), ctx.blind_rotate_plan(400), ctx.blind_rotate_plan(10)
+            assert big["kernel"].startswith("pair") and big["waves_per_team"] == 1, big
+            assert small["kernel"] == "team" and small["waves_per_team"] == 2, small
+            assert tiny["kernel"].startswith("wide"), tiny
+            got = ctx.bootstrap(lwe, tv)
+            acc = ctx.blind_rotate(lwe, tv)
+            ctx.set_kernel_shape(m.SHAPE_TEAM)     # slices of 100: below the wide team's limit, so force the team
+            assert ctx.blind_rotate_plan(100)["kernel"] == "team"
+            by_team = np.concatenate([ctx.bootstrap(lwe[i:i + 100], tv) for i in range(0, 1700, 100)])
+            ctx.set_kernel_shape(m.SHAPE_AUTO)
+            by_wide = np.concatenate([ctx.bootstrap(lwe[i:i + 10], tv) for i in range(0, 200, 10)])
+        assert np.array_equal(got, by_team)
+        assert np.array_equal(got[:200], by_wide)
+        with oracle.decomposer_aligned(aligned):
+            for b in (0, 1, 850, 1699):
+                want, tr = oracle.bootstrap(p, lwe[b], bsk, ksk, tv, trace=True)
+                assert np.array_equal(got[b], want), (aligned, b)
+                assert np.array_equal(acc[b], tr["acc_final"]), (aligned, b)

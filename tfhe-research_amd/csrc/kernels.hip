@@ -472,7 +472,7 @@ struct RotateKernelPair {
 #define TFHE_PAIR_KERNEL 1  // 0: A/B builds that keep the two-wave team at N = 512, k = 1 (the key keeps the pair layout)
 #endif
 template <class F, int LOGN, int K>
-using RotateKernelOf = typename std::conditional<(TFHE_PAIR_KERNEL && pair_shape<F, LOGN, K>()), RotateKernelPair<LOGN, K>, RotateKernel<F, LOGN, K>>::type;
+using PairOrTeamKernel = typename std::conditional<(TFHE_PAIR_KERNEL && pair_shape<F, LOGN, K>()), RotateKernelPair<LOGN, K>, RotateKernel<F, LOGN, K>>::type;
 
 // ------------------------------------------------------------------------------ blind rotation, wide team
 // The latency shape (pbs_wave.h::blind_rotate_team_wide): 2 (K+1) waves per sample -- wave (c, q) transforms half of
@@ -1117,9 +1117,8 @@ inline int current_device_slot() {
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
   return dev;
 }
-template <class F, int LOGN, int K>
+template <class RK>
 hipError_t resident_teams(unsigned* out) {
-  using RK = RotateKernelOf<F, LOGN, K>;
   static std::atomic<unsigned> cached[kMaxDevices];
   const int dev = current_device_slot();
   unsigned capacity = cached[dev].load(std::memory_order_acquire);
@@ -1134,6 +1133,24 @@ hipError_t resident_teams(unsigned* out) {
   }
   *out = capacity;
   return hipSuccess;
+}
+
+// Which kernel rotates a batch of the PAIR shape (N = 512, k = 1, complex transform) that is too large for the wide team:
+// one wave per sample takes ~2x the time of a two-wave team to finish ONE sample, and 2,048 of them fill the chip -- so up
+// to what the chip holds as two-wave teams (1,536 samples) the team is faster (1,024 samples: 2.96 against 4.2 ms); above,
+// the pair kernel's third fewer LDS cycles and 8 instead of 6 samples per CU win (4,096: 9.2 against 10.0 ms;
+// profiles/r04_kernel_ab.txt).  TFHE_BR_PAIR_MIN overrides the threshold (batches >= it take the pair kernel).
+template <class F, int LOGN, int K>
+bool use_pair_kernel(size_t batch) {
+  if constexpr (!(TFHE_PAIR_KERNEL && pair_shape<F, LOGN, K>())) {
+    return false;
+  } else {
+    static const long env_min = std::getenv("TFHE_BR_PAIR_MIN") ? std::atol(std::getenv("TFHE_BR_PAIR_MIN")) : -1;
+    if (env_min >= 0) return batch >= (size_t)env_min;
+    unsigned team_capacity = 0;
+    if (resident_teams<RotateKernel<F, LOGN, K>>(&team_capacity) != hipSuccess) return true;
+    return batch > (size_t)team_capacity * RotateKernel<F, LOGN, K>::kSamples;
+  }
 }
 
 // The wide team (blind_rotate_wide_kernel) is offered for the complex transform up to N = 1024 while its row buffers fit
@@ -1199,17 +1216,14 @@ hipError_t launch_blind_rotate_wide(hipStream_t s, const PbsParams& P, const typ
   }
 }
 
-template <class F, int LOGN, int K>
-hipError_t plan_blind_rotate(const PbsParams& P, size_t batch, bool can_park, bool have_side, launch::BlindRotatePlanInfo* out, int shape) {
-  if constexpr (!field_shape_ok<F, LOGN>()) {
-    return hipErrorInvalidValue;
-  } else {
+template <class RK, class F, int LOGN, int K>
+hipError_t plan_blind_rotate_with(const PbsParams& P, size_t batch, bool can_park, bool have_side, launch::BlindRotatePlanInfo* out, int shape) {
+  {
     using C = TeamCfg<F, LOGN, K>;
-    using RK = RotateKernelOf<F, LOGN, K>;
     static std::atomic<unsigned long long> lds_done{0};
     hipError_t e = allow_lds(RK::get(), RK::kLds, lds_done);
     unsigned capacity = 0;
-    if (e == hipSuccess) e = resident_teams<F, LOGN, K>(&capacity);
+    if (e == hipSuccess) e = resident_teams<RK>(&capacity);
     if (e != hipSuccess) return e;
     const size_t key_bytes = (size_t)P.n * (K + 1) * P.levels * (K + 1) * F::kParts * C::N * 8;
     const BlindRotatePlan plan = blind_rotate_plan<F>(batch, can_park, have_side, P.n, key_bytes, (u32)LOGN, (size_t)capacity * RK::kSamples);
@@ -1231,26 +1245,28 @@ hipError_t plan_blind_rotate(const PbsParams& P, size_t batch, bool can_park, bo
 }
 
 template <class F, int LOGN, int K>
-hipError_t launch_blind_rotate(hipStream_t s, const PbsParams& P, const void* tw_v, const u32* lwe_in,
-                               size_t batch, const u32* tv, size_t tv_stride, const void* bsk_v,
-                               u32* glwe_out, u32* lwe_extracted, u32* state, const launch::SideStream* side, int shape) {
+hipError_t plan_blind_rotate(const PbsParams& P, size_t batch, bool can_park, bool have_side, launch::BlindRotatePlanInfo* out, int shape) {
   if constexpr (!field_shape_ok<F, LOGN>()) {
-    return hipErrorInvalidValue;  // the context never picks such a field (capi.cpp)
+    return hipErrorInvalidValue;
   } else {
+    if (use_pair_kernel<F, LOGN, K>(batch))
+      return plan_blind_rotate_with<PairOrTeamKernel<F, LOGN, K>, F, LOGN, K>(P, batch, can_park, have_side, out, shape);
+    return plan_blind_rotate_with<RotateKernel<F, LOGN, K>, F, LOGN, K>(P, batch, can_park, have_side, out, shape);
+  }
+}
+
+template <class RK, class F, int LOGN, int K>
+hipError_t launch_blind_rotate_with(hipStream_t s, const PbsParams& P, const typename F::elem* tw, const u32* lwe_in,
+                                    size_t batch, const u32* tv, size_t tv_stride, const typename F::elem* bsk,
+                                    u32* glwe_out, u32* lwe_extracted, u32* state, const launch::SideStream* side) {
+  {
     using C = TeamCfg<F, LOGN, K>;
-    auto tw = static_cast<const typename F::elem*>(tw_v);
-    auto bsk = static_cast<const typename F::elem*>(bsk_v);
-    if constexpr (wide_shape_ok<F, LOGN, K>()) {
-      if (batch <= wide_max_batch<F, LOGN, K>(P, shape))
-        return launch_blind_rotate_wide<F, LOGN, K>(s, P, tw, lwe_in, batch, tv, tv_stride, bsk, glwe_out, lwe_extracted);
-    }
-    using RK = RotateKernelOf<F, LOGN, K>;
     auto kern = RK::get();
     static std::atomic<unsigned long long> lds_done{0};
     hipError_t e = allow_lds(kern, RK::kLds, lds_done);
     if (e != hipSuccess) return e;
     unsigned capacity = 0;
-    if ((e = resident_teams<F, LOGN, K>(&capacity)) != hipSuccess) return e;
+    if ((e = resident_teams<RK>(&capacity)) != hipSuccess) return e;
     // a second stream cannot be forked inside a stream capture that the caller ends on `s` alone without it joining;
     // it does join (below), but a capture is no place for a measured policy: one stream there
     bool have_side = side && side->stream && side->fork && side->join;
@@ -1292,6 +1308,27 @@ hipError_t launch_blind_rotate(hipStream_t s, const PbsParams& P, const void* tw
       if ((e = hipStreamWaitEvent(s, side->join, 0)) != hipSuccess) return e;
     }
     return hipSuccess;
+  }
+}
+
+template <class F, int LOGN, int K>
+hipError_t launch_blind_rotate(hipStream_t s, const PbsParams& P, const void* tw_v, const u32* lwe_in,
+                               size_t batch, const u32* tv, size_t tv_stride, const void* bsk_v,
+                               u32* glwe_out, u32* lwe_extracted, u32* state, const launch::SideStream* side, int shape) {
+  if constexpr (!field_shape_ok<F, LOGN>()) {
+    return hipErrorInvalidValue;  // the context never picks such a field (capi.cpp)
+  } else {
+    auto tw = static_cast<const typename F::elem*>(tw_v);
+    auto bsk = static_cast<const typename F::elem*>(bsk_v);
+    if constexpr (wide_shape_ok<F, LOGN, K>()) {
+      if (batch <= wide_max_batch<F, LOGN, K>(P, shape))
+        return launch_blind_rotate_wide<F, LOGN, K>(s, P, tw, lwe_in, batch, tv, tv_stride, bsk, glwe_out, lwe_extracted);
+    }
+    if (use_pair_kernel<F, LOGN, K>(batch))
+      return launch_blind_rotate_with<PairOrTeamKernel<F, LOGN, K>, F, LOGN, K>(s, P, tw, lwe_in, batch, tv, tv_stride, bsk, glwe_out,
+                                                                               lwe_extracted, state, side);
+    return launch_blind_rotate_with<RotateKernel<F, LOGN, K>, F, LOGN, K>(s, P, tw, lwe_in, batch, tv, tv_stride, bsk, glwe_out,
+                                                                          lwe_extracted, state, side);
   }
 }
 
