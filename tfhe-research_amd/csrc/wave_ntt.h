@@ -386,9 +386,69 @@ TFHE_HD int exchange_slot(int tid, int r) {
 // NS polynomials at once (ntt_transpose_multi): polynomial s goes through the buffer of context c[s]; the
 // contexts differ only in the buffer they select, and the waits and barriers are shared -- all stores, one
 // synchronisation, all loads -- so two polynomials cost one set of barriers (and one LDS round trip of latency).
+// A transpose between ADJACENT windows exchanges register-index bit i with thread-index bit min(LO_FROM, LO_TO) + i.  Where
+// those thread bits are lane bits 4 and 5 -- rows of 16 lanes and halves of the wave -- gfx950 does the exchange in
+// registers: v_permlane16_swap_b32 a, b swaps the odd rows of a with the even rows of b, v_permlane32_swap_b32 the upper
+// half of a with the lower half of b: exactly "the lanes whose bit is 1 hand their a over for the b of the lanes whose bit
+// is 0", one instruction per dword pair and bit -- 16 VALU instructions for a two-bit window of four 16-byte elements
+// instead of four stores and four loads through the LDS path (74 cycles of it, plus the round trip).  Taken where the
+// kernel has VALU issue to spare and the LDS path is the busier pipe (TFHE_SWAP_TRANSPOSE: the two-bit windows of the
+// complex transform at N = 512 with k = 2 and at N = 2048; profiles/r04_kernel_ab.txt).  The host emulator keeps the LDS
+// path (same values).
+#ifndef TFHE_SWAP_TRANSPOSE
+#define TFHE_SWAP_TRANSPOSE 1
+#endif
+template <int LOGN, int G, int LO_FROM, int LO_TO>
+constexpr bool swap_transpose_shape() {
+  constexpr int e = NttShape<LOGN, G>::kEBits;
+  constexpr int lo = LO_FROM < LO_TO ? LO_FROM : LO_TO, hi = LO_FROM < LO_TO ? LO_TO : LO_FROM;
+  return TFHE_SWAP_TRANSPOSE && G >= 1 && e == 2 && hi - lo == e && lo == 4;  // exchanged thread bits: exactly lane bits 4, 5
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class Elem, int E>
+__device__ __forceinline__ void swap_transpose_bits45(Elem (&x)[E]) {
+  static_assert(E == 4, "two register-index bits");
+  constexpr int W = (int)(sizeof(Elem) / 4);
+  // (the elements' words are moved through u32 copies: the swaps are inline assembly on 32-bit registers, and a cast of an
+  // element's address to u32* would be an aliasing violation the optimiser may act on)
+  u32 w[E][W];
+#pragma unroll
+  for (int r = 0; r < E; ++r) __builtin_memcpy(w[r], &x[r], sizeof(Elem));
+  // register bit 0 <-> lane bit 4, register bit 1 <-> lane bit 5
+  // (the compiler's builtins, not inline assembly: the hazard recogniser then sees the instructions -- a swap that reads a
+  // register a VALU instruction has just written needs wait states, and an opaque asm statement gets none: the inline form
+  // returned wrong words at N = 512 and right ones at N = 2048)
+#pragma unroll
+  for (int r0 = 0; r0 < E; r0 += 2)
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+      const auto sw = __builtin_amdgcn_permlane16_swap(w[r0][i], w[r0 + 1][i], false, false);
+      w[r0][i] = sw[0];
+      w[r0 + 1][i] = sw[1];
+    }
+#pragma unroll
+  for (int r0 = 0; r0 < 2; ++r0)
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+      const auto sw = __builtin_amdgcn_permlane32_swap(w[r0][i], w[r0 + 2][i], false, false);
+      w[r0][i] = sw[0];
+      w[r0 + 2][i] = sw[1];
+    }
+#pragma unroll
+  for (int r = 0; r < E; ++r) __builtin_memcpy(&x[r], w[r], sizeof(Elem));
+}
+#endif
+
 template <class F, int LOGN, int G, int LO_FROM, int LO_TO, bool SKIP_LEAD = false, int NS, class Ctx>
 TFHE_HD void ntt_transpose_multi(const Ctx (&c)[NS], typename F::elem (&x)[NS][NttShape<LOGN, G>::kE]) {
   constexpr int E = NttShape<LOGN, G>::kE;
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (swap_transpose_shape<LOGN, G, LO_FROM, LO_TO>()) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) swap_transpose_bits45<typename F::elem, E>(x[s]);
+    return;
+  }
+#endif
   constexpr bool WRITES_CROSS = G > 1 && LO_FROM > 6;
   constexpr bool READS_CROSS = G > 1 && LO_TO > 6;
   static_assert(!(WRITES_CROSS && READS_CROSS), "one of the two windows is a low one");
