@@ -398,42 +398,80 @@ TFHE_HD int exchange_slot(int tid, int r) {
 #ifndef TFHE_SWAP_TRANSPOSE
 #define TFHE_SWAP_TRANSPOSE 1
 #endif
+// Which lane bits may be exchanged in registers (TFHE_SWAP_LOW_BIT: the lowest one; 6 = never): bits 5 and 4 by the permlane
+// swaps (1 instruction per dword pair), bits 3 and 2 by bank-masked DPP moves -- a row of 16 lanes is four banks of 4, lane bit
+// 2 picks the odd banks, lane bit 3 the upper two, so "the lanes whose bit is 0 take their partner's a into b" is ONE
+// v_mov_b32_dpp whose bank mask leaves the other lanes' b alone (2 instructions per dword pair) --, bits 1 and 0 by quad
+// permutes and selects (4 per pair: measured slower than LDS, profiles/r04_kernel_ab.txt, so the default stops at bit 2).
+// Per shape (TFHE_SWAP_E8: also for the three-bit windows of 8 elements per lane): see swap_transpose_low_bit.
+#ifndef TFHE_SWAP_LOW_BIT
+#define TFHE_SWAP_LOW_BIT 2
+#endif
+#ifndef TFHE_SWAP_E8
+#define TFHE_SWAP_E8 0
+#endif
 template <int LOGN, int G, int LO_FROM, int LO_TO>
-constexpr bool swap_transpose_shape() {
+constexpr int swap_transpose_low_bit() {  // lowest exchanged lane bit, or -1: through LDS
   constexpr int e = NttShape<LOGN, G>::kEBits;
   constexpr int lo = LO_FROM < LO_TO ? LO_FROM : LO_TO, hi = LO_FROM < LO_TO ? LO_TO : LO_FROM;
-  return TFHE_SWAP_TRANSPOSE && G >= 1 && e == 2 && hi - lo == e && lo == 4;  // exchanged thread bits: exactly lane bits 4, 5
+  // adjacent windows of lane bits only (thread bit = lane bit below 6; half-wave groups: below 5)
+  if (!TFHE_SWAP_TRANSPOSE || hi - lo != e || lo + e > (G == 0 ? 5 : 6)) return -1;
+  if (e == 3 && !TFHE_SWAP_E8) return -1;
+  if (e != 2 && e != 3) return -1;
+  return lo >= TFHE_SWAP_LOW_BIT ? lo : -1;
+}
+template <int LOGN, int G, int LO_FROM, int LO_TO>
+constexpr bool swap_transpose_shape() {
+  return swap_transpose_low_bit<LOGN, G, LO_FROM, LO_TO>() >= 0;
 }
 #if defined(__HIP_DEVICE_COMPILE__)
-template <class Elem, int E>
-__device__ __forceinline__ void swap_transpose_bits45(Elem (&x)[E]) {
-  static_assert(E == 4, "two register-index bits");
+// exchange register-index bit RB with lane bit LB for all E registers of 16- or 8-byte elements (the words go through u32
+// copies: a cast of an element's address to u32* would be an aliasing violation; the swaps and moves are the compiler's
+// builtins, not inline assembly -- the hazard recogniser has to see them: issued as asm statements the swaps returned wrong
+// words at N = 512)
+template <int RB, int LB, int E, int W>
+__device__ __forceinline__ void exchange_register_bit_with_lane_bit(u32 (&w)[E][W], int lane) {
+#pragma unroll
+  for (int r0 = 0; r0 < E; ++r0) {
+    if ((r0 >> RB) & 1) continue;
+    const int r1 = r0 | (1 << RB);
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+      const u32 a = w[r0][i], b = w[r1][i];  // lanes whose bit is 0 hand over b for their partner's a
+      if constexpr (LB == 5) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+        w[r0][i] = sw[0];
+        w[r1][i] = sw[1];
+      } else if constexpr (LB == 4) {
+        const auto sw = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+        w[r0][i] = sw[0];
+        w[r1][i] = sw[1];
+      } else if constexpr (LB == 3) {  // row_ror:8 = lane ^ 8; banks 0,1 have bit 3 clear
+        w[r1][i] = (u32)__builtin_amdgcn_update_dpp((int)b, (int)a, 0x128, 0xF, 0x3, false);
+        w[r0][i] = (u32)__builtin_amdgcn_update_dpp((int)a, (int)b, 0x128, 0xF, 0xC, false);
+      } else if constexpr (LB == 2) {  // row_shl:4 reads lane + 4 (banks 0,2: bit 2 clear), row_shr:4 lane - 4
+        w[r1][i] = (u32)__builtin_amdgcn_update_dpp((int)b, (int)a, 0x104, 0xF, 0x5, false);
+        w[r0][i] = (u32)__builtin_amdgcn_update_dpp((int)a, (int)b, 0x114, 0xF, 0xA, false);
+      } else {  // quad_perm:[1,0,3,2] = lane ^ 1, quad_perm:[2,3,0,1] = lane ^ 2, and selects
+        constexpr int ctrl = LB == 0 ? 0xB1 : 0x4E;
+        const bool bit = ((lane >> LB) & 1) != 0;
+        const u32 pa = (u32)__builtin_amdgcn_update_dpp(0, (int)a, ctrl, 0xF, 0xF, true);
+        const u32 pb = (u32)__builtin_amdgcn_update_dpp(0, (int)b, ctrl, 0xF, 0xF, true);
+        w[r1][i] = bit ? b : pa;
+        w[r0][i] = bit ? pb : a;
+      }
+    }
+  }
+}
+template <class Elem, int E, int LOW>
+__device__ __forceinline__ void swap_transpose(Elem (&x)[E], int lane) {
   constexpr int W = (int)(sizeof(Elem) / 4);
-  // (the elements' words are moved through u32 copies: the swaps are inline assembly on 32-bit registers, and a cast of an
-  // element's address to u32* would be an aliasing violation the optimiser may act on)
   u32 w[E][W];
 #pragma unroll
   for (int r = 0; r < E; ++r) __builtin_memcpy(w[r], &x[r], sizeof(Elem));
-  // register bit 0 <-> lane bit 4, register bit 1 <-> lane bit 5
-  // (the compiler's builtins, not inline assembly: the hazard recogniser then sees the instructions -- a swap that reads a
-  // register a VALU instruction has just written needs wait states, and an opaque asm statement gets none: the inline form
-  // returned wrong words at N = 512 and right ones at N = 2048)
-#pragma unroll
-  for (int r0 = 0; r0 < E; r0 += 2)
-#pragma unroll
-    for (int i = 0; i < W; ++i) {
-      const auto sw = __builtin_amdgcn_permlane16_swap(w[r0][i], w[r0 + 1][i], false, false);
-      w[r0][i] = sw[0];
-      w[r0 + 1][i] = sw[1];
-    }
-#pragma unroll
-  for (int r0 = 0; r0 < 2; ++r0)
-#pragma unroll
-    for (int i = 0; i < W; ++i) {
-      const auto sw = __builtin_amdgcn_permlane32_swap(w[r0][i], w[r0 + 2][i], false, false);
-      w[r0][i] = sw[0];
-      w[r0 + 2][i] = sw[1];
-    }
+  exchange_register_bit_with_lane_bit<0, LOW, E, W>(w, lane);
+  exchange_register_bit_with_lane_bit<1, LOW + 1, E, W>(w, lane);
+  if constexpr (E == 8) exchange_register_bit_with_lane_bit<2, LOW + 2, E, W>(w, lane);
 #pragma unroll
   for (int r = 0; r < E; ++r) __builtin_memcpy(&x[r], w[r], sizeof(Elem));
 }
@@ -444,8 +482,9 @@ TFHE_HD void ntt_transpose_multi(const Ctx (&c)[NS], typename F::elem (&x)[NS][N
   constexpr int E = NttShape<LOGN, G>::kE;
 #if defined(__HIP_DEVICE_COMPILE__)
   if constexpr (swap_transpose_shape<LOGN, G, LO_FROM, LO_TO>()) {
+    constexpr int LOW = swap_transpose_low_bit<LOGN, G, LO_FROM, LO_TO>();
 #pragma unroll
-    for (int s = 0; s < NS; ++s) swap_transpose_bits45<typename F::elem, E>(x[s]);
+    for (int s = 0; s < NS; ++s) swap_transpose<typename F::elem, E, LOW>(x[s], c[0].tid());
     return;
   }
 #endif
