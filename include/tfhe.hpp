@@ -161,6 +161,9 @@ class Engine {
   // k*N+1 words at the boundary).  Defaults are the reference's behaviour.
   void set_decomposer_alignment(bool aligned) { check_pool(tfhe_pool_set_decomposer_alignment(pool_.get(), aligned)); }
   void set_bootstrap_order(bool ks_first) { check_pool(tfhe_pool_set_bootstrap_order(pool_.get(), ks_first)); }
+  // TFHE_SHAPE_AUTO (default: by batch size), TFHE_SHAPE_WIDE (the latency shape: the reference's bootstrap() takes ONE
+  // ciphertext, bootstrapping.rs:58-65) or TFHE_SHAPE_TEAM for every blind rotation of the engine; same bits either way
+  void set_kernel_shape(int shape) { check_pool(tfhe_pool_set_kernel_shape(pool_.get(), shape)); }
 
   const TfheParams& params() const { return params_; }
   tfhe_context* raw() const { return ctx_; }        // the first device's context (single-ciphertext calls)

@@ -385,6 +385,7 @@ int tfhe_pool_shard(const tfhe_pool *pool, size_t batch, size_t member, size_t *
  * (reserve sizes each member for its slice of `max_batch`). */
 int tfhe_pool_set_decomposer_alignment(tfhe_pool *pool, int aligned);
 int tfhe_pool_set_bootstrap_order(tfhe_pool *pool, int ks_first);
+int tfhe_pool_set_kernel_shape(tfhe_pool *pool, int shape); /* tfhe_context_set_kernel_shape for every member */
 int tfhe_pool_reserve(tfhe_pool *pool, size_t max_batch);
 int tfhe_pool_synchronize(tfhe_pool *pool);
 /* BootstrappingKey upload, layouts as tfhe_load_bootstrapping_key: host pointers, or (_device) pointers on member

@@ -42,6 +42,7 @@ extern "C" {
                                  test_vector_poly: *const u32, tv_count: usize, lwe_out: *mut u32) -> c_int;
     fn tfhe_pool_gate_batch(pool: *mut TfhePool, truth: *const u32, ct0: *const u32, ct1: *const u32,
                             batch: usize, lwe_out: *mut u32) -> c_int;
+    fn tfhe_pool_set_kernel_shape(pool: *mut TfhePool, shape: c_int) -> c_int;
     fn tfhe_last_error(ctx: *const TfheContext) -> *const c_char;
     fn tfhe_bootstrap_batch(ctx: *mut TfheContext, lwe_in: *const u32, batch: usize,
                             test_vector_poly: *const u32, tv_count: usize, lwe_out: *mut u32) -> c_int;
@@ -118,6 +119,18 @@ impl GpuBootstrappingKey {
         let (pool, ctx) = Self::create(params, devices);
         check_pool(pool, unsafe { tfhe_pool_load_bootstrapping_key_bmmp(pool, bsk_bmmp.as_ptr(), ksk.as_ptr()) }, "load BMMP key");
         GpuBootstrappingKey { pool, ctx, params: *params }
+    }
+}
+
+/// Kernel shape of the blind rotation (`tfhe_context_set_kernel_shape`): `Auto` picks by batch -- a single `bootstrap()`
+/// (the crate's own call, bootstrapping.rs:58-65) or a narrow gate level gets the wide team, large batches the throughput
+/// kernels; the bits are the same.
+#[derive(Clone, Copy)]
+pub enum KernelShape { Auto = 0, Wide = 1, Team = 2 }
+
+impl GpuBootstrappingKey {
+    pub fn set_kernel_shape(&self, shape: KernelShape) {
+        check_pool(self.pool, unsafe { tfhe_pool_set_kernel_shape(self.pool, shape as c_int) }, "set kernel shape");
     }
 }
 

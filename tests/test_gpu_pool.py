@@ -278,3 +278,22 @@ def test_sharded_bootstrap_over_rccl_two_ranks(tmp_path):
                          capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "rccl two-rank OK" in out.stdout
+
+
+def test_pool_kernel_shape_reaches_every_member(oracle):
+    """tfhe_pool_set_kernel_shape: every member's blind rotations take the forced shape; same words"""
+    m = pkg()
+    p = oracle.Params(1, 10, 6, oracle.Decomposer(8, 4))
+    lwe, bsk, ksk, tv = oracle.synthetic_inputs(p, 12, cfg_index=71)
+    outs = {}
+    for shape in (m.SHAPE_AUTO, m.SHAPE_WIDE, m.SHAPE_TEAM):
+        with m.Pool(to_pkg_params(p), [0, 0]) as pool:
+            pool.set_kernel_shape(shape)
+            pool.load_bootstrapping_key(bsk, ksk)
+            for i in range(2):
+                plan = pool.member(i).blind_rotate_plan(6)
+                assert plan["kernel"].startswith("team" if shape == m.SHAPE_TEAM else "wide"), (shape, i, plan)
+            outs[shape] = pool.bootstrap(lwe, tv)
+    assert np.array_equal(outs[m.SHAPE_WIDE], outs[m.SHAPE_TEAM]) and np.array_equal(outs[m.SHAPE_AUTO], outs[m.SHAPE_TEAM])
+    for b in (0, 5, 6, 11):
+        assert np.array_equal(outs[m.SHAPE_WIDE][b], oracle.bootstrap(p, lwe[b], bsk, ksk, tv)), b

@@ -965,6 +965,9 @@ class Pool:
     def set_decomposer_alignment(self, aligned: bool):
         self._check(lib().tfhe_pool_set_decomposer_alignment(self._h, C.c_int(int(aligned))))
 
+    def set_kernel_shape(self, shape: int):
+        self._check(lib().tfhe_pool_set_kernel_shape(self._h, C.c_int(int(shape))))
+
     def set_bootstrap_order(self, ks_first: bool):
         self._check(lib().tfhe_pool_set_bootstrap_order(self._h, C.c_int(int(ks_first))))
         self._ks_first = bool(ks_first)

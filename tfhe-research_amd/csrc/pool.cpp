@@ -128,6 +128,15 @@ int tfhe_pool_set_decomposer_alignment(tfhe_pool* pool, int aligned) {
   return TFHE_OK;
 }
 
+int tfhe_pool_set_kernel_shape(tfhe_pool* pool, int shape) {
+  if (!pool) return TFHE_ERR_INVALID_ARGUMENT;
+  for (size_t i = 0; i < pool->members.size(); ++i) {
+    int st = tfhe_context_set_kernel_shape(pool->members[i], shape);
+    if (st) return member_fail(pool, i, st);
+  }
+  return TFHE_OK;
+}
+
 int tfhe_pool_set_bootstrap_order(tfhe_pool* pool, int ks_first) {
   if (!pool) return TFHE_ERR_INVALID_ARGUMENT;
   for (size_t i = 0; i < pool->members.size(); ++i) {
