@@ -648,6 +648,11 @@ def test_complex_transform_lds_layouts_in_the_bank_model():
     assert all(v == (0, 0) for lo, v in c8.items() if lo != 0) and c8[0][0] == 0 and c8[0][1] <= 32
     c10 = ntt_model.conflicts_b128(10, 4)
     assert all(v == (0, 0) for lo, v in c10.items() if lo != 0) and c10[0][0] == 0 and c10[0][1] <= 4 * 32
+    # the pair kernel's half-wave shape (32 lanes x 8 elements): reads and two windows' stores conflict free, the third
+    # window's stores two-way in every group: 8 extra LDS-array cycles per store instruction = 16 against the ~14 cycles
+    # the store's register transfer takes anyway (profiles/r04_lds_rates_gfx950.txt)
+    half, worst_store = ntt_model.conflicts_b128_half()
+    assert half[5] == (0, 0) and half[2] == (0, 0) and half[0] == (0, 32) and worst_store == 8
 
 
 def test_key_word_split_has_no_signed_overflow(emu):

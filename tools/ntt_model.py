@@ -336,6 +336,42 @@ def conflicts_b128(logn, g=1):
     return out
 
 
+def swizzle16_half(j):
+    """wave_ntt.h::ntt_swizzle<8, 0>: 256 16-byte elements over HALF a wave (32 lanes x 8 elements: the pair kernel)"""
+    return j ^ (((j >> 4) & 1) * 1) ^ (((j >> 5) & 1) * 4) ^ (((j >> 7) & 1) * 10)
+
+
+def conflicts_b128_half():
+    """the pair kernel's transposes (256 points, 32 lanes x 8 registers, windows [5,8) [2,5) [0,3)) under the b128 banking
+    rules: a half-wave is two of the four read lane groups and four of the eight write groups, and the other half touches
+    another 4 KiB region with the same pattern in ITS groups.  -> {window low: (read extra cycles, write extra cycles)}
+    summed over the 8 registers; and the worst extra cycles of one store instruction (both halves: 8 groups)"""
+    logn, e = 8, 3
+    assert sorted(swizzle16_half(j) for j in range(1 << logn)) == list(range(1 << logn))
+    rg = [g for g in B128_READ_GROUPS if max(g) < 32]
+    wg = [g for g in B128_WRITE_GROUPS if max(g) < 32]
+    out, worst_store = {}, 0
+    for lo in (5, 2, 0):
+        er = ew = 0
+        for r in range(1 << e):
+            addr = [swizzle16_half(((l >> lo) << (lo + e)) | (r << lo) | (l & ((1 << lo) - 1))) for l in range(32)]
+            one = 0
+            for groups, slots, kind in ((rg, 16, "r"), (wg, 8, "w")):
+                for grp in groups:
+                    seen = {}
+                    for l in grp:
+                        seen.setdefault(addr[l] % slots, set()).add(addr[l])
+                    extra = max(len(v) for v in seen.values()) - 1
+                    if kind == "r":
+                        er += extra
+                    else:
+                        ew += extra
+                        one += extra
+            worst_store = max(worst_store, 2 * one)
+        out[lo] = (er, ew)
+    return out, worst_store
+
+
 if __name__ == "__main__":
     for logn in (9, 10, 11):
         print(logn, selfcheck(logn))
@@ -343,4 +379,5 @@ if __name__ == "__main__":
     print("11 x4 waves", conflicts_grouped(11, 4))
     print("complex transform, 512 points (N = 1024):", conflicts_b128(9))
     print("complex transform, 256 points (N = 512):", conflicts_b128(8))
-    print("complex transform, 1024 points over 4 waves (N = 2048, emulator only):", conflicts_b128(10, 4))
+    print("complex transform, 1024 points over 4 waves (N = 2048):", conflicts_b128(10, 4))
+    print("pair kernel, 256 points over half a wave (N = 512, k = 1):", conflicts_b128_half())
