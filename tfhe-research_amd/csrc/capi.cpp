@@ -219,13 +219,15 @@ int adopt_prepared_key(tfhe_context* dst, const tfhe_context* src) {
   if (std::memcmp(&dst->params, &src->params, sizeof(tfhe_params)) != 0 || dst->field != src->field ||
       dst->aligned != src->aligned)
     return fail(dst, TFHE_ERR_INVALID_PARAMS, "pool members must share parameters, backend and decomposer alignment");
+  // from here on dst has NO key until the copies are enqueued: a failure half way must not leave it answering under the
+  // key it held before
+  dst->have_key = false;
   HIP_TRY(dst, hipSetDevice(dst->device));
   const size_t ggsws = src->bsk_ggsws;
   const size_t bsk_bytes = ggsws * src->R * (src->params.glwe_dimension + 1) * (size_t)src->parts * src->N * sizeof(u64);
   const size_t ksk_bytes = (size_t)src->big_n * src->ks.levels * ((size_t)src->params.lwe_dimension + 1) * sizeof(u32);
   if (dst->d_bsk && dst->bsk_ggsws != ggsws) {
     HIP_TRY(dst, hipStreamSynchronize(dst->stream));
-    dst->have_key = false;
     hipError_t e = hipFree(dst->d_bsk);
     dst->d_bsk = nullptr;
     if (e != hipSuccess) return hip_fail(dst, e, "hipFree(bsk)");
@@ -680,9 +682,11 @@ static int load_key_common(tfhe_context* ctx, const u32* d_bsk_raw, const u32* d
   const size_t ggsws = key_ggsws(ctx, bmmp);
   const size_t bsk_polys = ggsws * ctx->R * (ctx->params.glwe_dimension + 1);
   const size_t ksk_words = (size_t)ctx->big_n * ctx->ks.levels * ((size_t)ctx->params.lwe_dimension + 1);
+  // the key buffers are overwritten in place: until the new key is complete the context holds none (a failure half way
+  // must not leave it bootstrapping under a half-written key)
+  ctx->have_key = false;
   if (ctx->d_bsk && ctx->bsk_ggsws != ggsws) {  // the other kind of key was loaded before
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->have_key = false;
     hipError_t e = hipFree(ctx->d_bsk);
     ctx->d_bsk = nullptr;
     if (e != hipSuccess) return hip_fail(ctx, e, "hipFree(bsk)");
@@ -712,7 +716,13 @@ static int load_key_host(tfhe_context* ctx, const uint32_t* bsk, const uint32_t*
   hipError_t e = hipMemcpy(d_raw, bsk, bsk_words * sizeof(u32), hipMemcpyHostToDevice);
   if (e == hipSuccess && !ctx->d_ksk)
     e = hipMalloc(reinterpret_cast<void**>(&ctx->d_ksk), ksk_words * sizeof(u32));
-  if (e == hipSuccess) e = hipMemcpy(ctx->d_ksk, ksk, ksk_words * sizeof(u32), hipMemcpyHostToDevice);
+  // the key-switching key is overwritten in place by a copy that does not order itself behind the context's stream:
+  // whatever was enqueued under the old key finishes first, and from here on the context holds no key
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) {
+    ctx->have_key = false;
+    e = hipMemcpy(ctx->d_ksk, ksk, ksk_words * sizeof(u32), hipMemcpyHostToDevice);
+  }
   if (e != hipSuccess) {
     (void)hipFree(d_raw);
     return hip_fail(ctx, e, "key upload");

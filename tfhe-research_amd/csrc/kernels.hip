@@ -1059,7 +1059,7 @@ hipError_t allow_lds(Kern kern, size_t bytes, std::atomic<unsigned long long>& d
 //   (Measured and dropped: the same blocking inside ONE persistent launch -- teams that are never re-dispatched never
 //   re-synchronise, 48 k at cfg3.)
 // Hence, at N <= 1024: batches above what the chip holds at once go out in groups of up to 131,072 samples over key slices
-// of 2 MiB, on two streams; smaller ones in one launch.  That holds for every field (two streams + slices at batch 4,096:
+// of half an L2 (l2_key_slice: 2 MiB on gfx950), on two streams; smaller ones in one launch.  That holds for every field (two streams + slices at batch 4,096:
 // fp64-p49 at the reference's defaults 54.2 k -> 60.7 k PBS/s, Goldilocks at cfg2 29.2 k -> 30.8 k, fp64-p42 at cfg2 75.6 k
 // -> 77.0 k).  At N = 2048: slices of 128 MiB if the key exceeds the Infinity Cache, one stream; the complex transform's
 // long batches in groups of 16,384.  Without a place to park accumulators (state == nullptr): whole rotations, 4,096
@@ -1076,6 +1076,28 @@ inline long env_number(const char* name) {
   const long v = env ? std::atol(env) : 0;
   return v > 0 ? v : 0;
 }
+constexpr int kMaxDevices = 64;
+inline int current_device_slot() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+  return dev;
+}
+// The key slice a segment launch walks: HALF of one L2 of the current device (an XCD's L2 on gfx950: 4 MiB, so 2 MiB -- the
+// size the sweeps of round 3 settled on: the other half holds what the teams stream beside the key), asked once per device.
+inline size_t l2_key_slice() {
+  static std::atomic<size_t> cached[kMaxDevices];
+  const int dev = current_device_slot();
+  size_t slice = cached[dev].load(std::memory_order_acquire);
+  if (slice == 0) {
+    int l2 = 0;
+    if (hipDeviceGetAttribute(&l2, hipDeviceAttributeL2CacheSize, dev) != hipSuccess || l2 <= 0) l2 = 4 << 20;
+    slice = (size_t)l2 / 2;
+    if (slice < ((size_t)1 << 20)) slice = (size_t)1 << 20;
+    if (slice > ((size_t)16 << 20)) slice = (size_t)16 << 20;
+    cached[dev].store(slice, std::memory_order_release);
+  }
+  return slice;
+}
 template <class F>
 inline BlindRotatePlan blind_rotate_plan(size_t batch, bool can_park, bool have_side, u32 n, size_t key_bytes, u32 log_n,
                                          size_t resident_samples) {
@@ -1089,14 +1111,14 @@ inline BlindRotatePlan blind_rotate_plan(size_t batch, bool can_park, bool have_
       slice = fits ? 0 : (size_t)128 << 20;
       if (F::kLogShrink && batch >= 16384) plan.chunk = 16384;
     } else if (batch > resident_samples) {
-      slice = (size_t)2 << 20;
+      slice = l2_key_slice();
       plan.chunk = 131072;
       plan.streams = have_side ? 2 : 1;
     } else {
       plan.chunk = batch ? batch : 1;
     }
     if (env_streams) plan.streams = have_side && env_streams >= 2 ? 2 : 1;
-    if (plan.streams == 2 && slice == 0) slice = (size_t)2 << 20;
+    if (plan.streams == 2 && slice == 0) slice = l2_key_slice();
     plan.segments = slice ? (u32)((key_bytes + slice - 1) / slice) : 1u;
     if (plan.segments > n / 4) plan.segments = n / 4;
     if (env_segments) plan.segments = (u32)env_segments;
@@ -1111,12 +1133,6 @@ inline BlindRotatePlan blind_rotate_plan(size_t batch, bool can_park, bool have_
 
 // teams of blind_rotate_kernel<F, LOGN, K> the CURRENT device holds at once (occupancy x CUs), asked once per
 // instantiation and device (a pool spans devices: nothing about one device is assumed of another)
-constexpr int kMaxDevices = 64;
-inline int current_device_slot() {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
-  return dev;
-}
 template <class RK>
 hipError_t resident_teams(unsigned* out) {
   static std::atomic<unsigned> cached[kMaxDevices];

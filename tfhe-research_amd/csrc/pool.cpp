@@ -170,6 +170,9 @@ int tfhe_pool_synchronize(tfhe_pool* pool) {
 
 // prepare once on member 0, replicate the prepared key: see the header of this file
 static int replicate_from_member0(tfhe_pool* pool) {
+  // no member keeps an older key while the new one travels: if a copy fails, the members it did not reach answer
+  // TFHE_ERR_NO_KEY instead of bootstrapping their slices under the key loaded before
+  for (size_t i = 1; i < pool->members.size(); ++i) pool->members[i]->have_key = false;
   for (size_t i = 1; i < pool->members.size(); ++i) {
     int st = tfhe::host::adopt_prepared_key(pool->members[i], pool->members[0]);
     if (st) return member_fail(pool, i, st);

@@ -1,0 +1,9 @@
+# GPU box: clocks and power of the literal / aligned cfg2 step, the whole -m gpu suite, both parts of the final profile
+set -u
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r04p; mkdir -p $O
+timeout -k 10 120 python tools/clock_watch.py cfg2 4 2>&1 | grep -v "amdgpu.ids" | tee $O/clock_watch_cfg2.txt
+timeout -k 10 700 python -m pytest tests -m gpu -x -q > $O/gpu_tests.log 2>&1; echo "pytest rc=$?" | tee -a $O/gpu_tests.log; tail -3 $O/gpu_tests.log
+bash tools/final_profile.sh > $O/final1.log 2>&1; echo "final1 rc=$?"
+bash tools/final_profile_2.sh > $O/final2.log 2>&1; echo "final2 rc=$?"
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
