@@ -24,4 +24,13 @@ typedef int64_t i64;
 
 constexpr int kWave = 64;  // CDNA wavefront width
 
+// s_setprio: the issue priority of this wave among the waves of its SIMD (0 = lowest, the state a wave starts in).
+// The host emulator runs one lane at a time: nothing to arbitrate.
+template <int PRIORITY>
+TFHE_HD void wave_priority() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_s_setprio(PRIORITY);
+#endif
+}
+
 }  // namespace tfhe

@@ -477,9 +477,26 @@ __device__ __forceinline__ void swap_transpose(Elem (&x)[E], int lane) {
 }
 #endif
 
+// Issue priority around a transpose through LDS (TFHE_TRANSPOSE_PRIORITY): a wave drops to priority 0 for the stores, the
+// wait and the loads of a transpose and runs everything else at priority 2, so the wave of a SIMD that is in a register pass
+// (pure VALU) issues ahead of the one that is moving data and waiting for it.  Measured per shape (blind rotation of 4,096,
+// profiles/r04_kernel_ab.txt section 11): the three-pass complex transforms with 8 elements per lane gain -- cfg2's team
+// 28.74 -> 27.95 ms (aligned 32.23 -> 31.92), cfg1's pair kernel 9.56 -> 9.28 -- the 4-element shapes, whose lane-local
+// transposes run in registers anyway, do not (cfg3 level, cfg5 +1 %): on for the former only.  (Raising the priority INSIDE
+// the transposes, a lower one for the multiply-accumulate or the operand read, and fixed different priorities per wave
+// slot were measured too: level or worse.)
+#ifndef TFHE_TRANSPOSE_PRIORITY
+#define TFHE_TRANSPOSE_PRIORITY 1
+#endif
+template <class Elem, int E>
+constexpr bool transpose_lowers_priority() {
+  return TFHE_TRANSPOSE_PRIORITY && sizeof(Elem) == 16 && E == 8;
+}
+
 template <class F, int LOGN, int G, int LO_FROM, int LO_TO, bool SKIP_LEAD = false, int NS, class Ctx>
 TFHE_HD void ntt_transpose_multi(const Ctx (&c)[NS], typename F::elem (&x)[NS][NttShape<LOGN, G>::kE]) {
   constexpr int E = NttShape<LOGN, G>::kE;
+  constexpr bool PRIO = transpose_lowers_priority<typename F::elem, E>();
 #if defined(__HIP_DEVICE_COMPILE__)
   if constexpr (swap_transpose_shape<LOGN, G, LO_FROM, LO_TO>()) {
     constexpr int LOW = swap_transpose_low_bit<LOGN, G, LO_FROM, LO_TO>();
@@ -495,6 +512,7 @@ TFHE_HD void ntt_transpose_multi(const Ctx (&c)[NS], typename F::elem (&x)[NS][N
   // (TFHE_PROBE_NO_TRANSPOSE: dev_switches.h -- a WRONG-BITS timing probe, TFHE_DEV_BUILD only)
   if (TFHE_PROBE_NO_TRANSPOSE) return;
   if (WRITES_CROSS && !SKIP_LEAD) c[0].poly_sync();
+  if constexpr (PRIO) wave_priority<0>();
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     typename F::elem* buf = c[s].scratch();
@@ -509,6 +527,7 @@ TFHE_HD void ntt_transpose_multi(const Ctx (&c)[NS], typename F::elem (&x)[NS][N
     for (int r = 0; r < E; ++r) x[s][r] = buf[ntt_swizzle<LOGN, G>(ntt_index<LOGN, G, LO_TO>(tid, r))];
   }
   if (READS_CROSS) c[0].poly_sync(); else c[0].wave_sync();
+  if constexpr (PRIO) wave_priority<2>();
 }
 
 template <class F, int LOGN, int G, int LO_FROM, int LO_TO, bool SKIP_LEAD = false, class Ctx>
