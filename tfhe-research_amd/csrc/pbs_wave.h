@@ -399,6 +399,8 @@ TFHE_HD void external_product_team_multi(const Ctx& c, const PbsParams& P, const
     // accumulator (key, key part) -- so that a piece of a digit spectrum is read from LDS once and
     // used for every key and part, and a key chunk is fetched once and used for every sample
     elem d[NS][CH];
+    constexpr bool MAC_LOW = mac_lowers_priority<elem, E>();  // wave_ntt.h: issue priority by phase
+    if constexpr (MAC_LOW) wave_priority<0>();
     static_for<0, CHUNKS>([&](auto ci_c) {
       constexpr int ci = decltype(ci_c)::value;
       constexpr int PIECES = E / CH;
@@ -438,6 +440,7 @@ TFHE_HD void external_product_team_multi(const Ctx& c, const PbsParams& P, const
             accum[s][q][r0 + r] = F::mul_add(d[s][r], kbuf[cur][r], accum[s][q][r0 + r]);
         }
     });
+    if constexpr (MAC_LOW) wave_priority<2>();
     if (!two && !LATE) c.team_sync();  // everyone is done reading before the next transform reuses the buffer
   }
 

@@ -477,20 +477,27 @@ __device__ __forceinline__ void swap_transpose(Elem (&x)[E], int lane) {
 }
 #endif
 
-// Issue priority around a transpose through LDS (TFHE_TRANSPOSE_PRIORITY): a wave drops to priority 0 for the stores, the
-// wait and the loads of a transpose and runs everything else at priority 2, so the wave of a SIMD that is in a register pass
-// (pure VALU) issues ahead of the one that is moving data and waiting for it.  Measured per shape (blind rotation of 4,096,
-// profiles/r04_kernel_ab.txt section 11): the three-pass complex transforms with 8 elements per lane gain -- cfg2's team
-// 28.74 -> 27.95 ms (aligned 32.23 -> 31.92), cfg1's pair kernel 9.56 -> 9.28 -- the 4-element shapes, whose lane-local
-// transposes run in registers anyway, do not (cfg3 level, cfg5 +1 %): on for the former only.  (Raising the priority INSIDE
-// the transposes, a lower one for the multiply-accumulate or the operand read, and fixed different priorities per wave
-// slot were measured too: level or worse.)
-#ifndef TFHE_TRANSPOSE_PRIORITY
-#define TFHE_TRANSPOSE_PRIORITY 1
+// Issue priority by phase (TFHE_PHASE_PRIORITY), complex transform only.  A wave drops to priority 0 while it MOVES data and
+// waits for it -- the stores, the wait and the loads of a transpose through LDS here; in the 4-element shapes also the
+// multiply-accumulate with its key loads and spectrum reads (pbs_wave.h) -- and runs its register passes, the digit chain
+// and everything else at priority 2: of the waves of a SIMD the one that has arithmetic to issue goes first.
+// Measured per shape (blind rotation of 4,096, ms; profiles/r04_kernel_ab.txt section 11):
+//   8 elements per lane: transposes low: cfg2's team 28.74 -> 27.95 (aligned 32.23 -> 31.92), cfg1's pair kernel 9.56 -> 9.28;
+//                        the multiply-accumulate low as well: worse (28.6) -- there it stays at 2;
+//   4 elements per lane: transposes low alone: cfg3 level, cfg5 +1 %; multiply-accumulate low alone: -1.3 % / -0.4 %;
+//                        BOTH: cfg3 50.16 -> 49.34, cfg5 169.2 -> 164.4.
+// (Raising the priority INSIDE the transposes, the operand read and the final update low too, and fixed different priorities
+// per wave slot: level or worse.)
+#ifndef TFHE_PHASE_PRIORITY
+#define TFHE_PHASE_PRIORITY 1
 #endif
 template <class Elem, int E>
 constexpr bool transpose_lowers_priority() {
-  return TFHE_TRANSPOSE_PRIORITY && sizeof(Elem) == 16 && E == 8;
+  return TFHE_PHASE_PRIORITY && sizeof(Elem) == 16 && (E == 8 || E == 4);
+}
+template <class Elem, int E>
+constexpr bool mac_lowers_priority() {
+  return TFHE_PHASE_PRIORITY && sizeof(Elem) == 16 && E == 4;
 }
 
 template <class F, int LOGN, int G, int LO_FROM, int LO_TO, bool SKIP_LEAD = false, int NS, class Ctx>
