@@ -399,7 +399,7 @@ TFHE_HD void external_product_team_multi(const Ctx& c, const PbsParams& P, const
     // accumulator (key, key part) -- so that a piece of a digit spectrum is read from LDS once and
     // used for every key and part, and a key chunk is fetched once and used for every sample
     elem d[NS][CH];
-    constexpr bool MAC_LOW = mac_lowers_priority<elem, E>();  // wave_ntt.h: issue priority by phase
+    constexpr bool MAC_LOW = mac_lowers_priority<elem, E>() && KEYS == 1;  // wave_ntt.h: issue priority by phase (not the unrolled rotation: measured worse)
     if constexpr (MAC_LOW) wave_priority<0>();
     static_for<0, CHUNKS>([&](auto ci_c) {
       constexpr int ci = decltype(ci_c)::value;

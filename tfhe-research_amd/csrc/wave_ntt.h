@@ -477,15 +477,17 @@ __device__ __forceinline__ void swap_transpose(Elem (&x)[E], int lane) {
 }
 #endif
 
-// Issue priority by phase (TFHE_PHASE_PRIORITY), complex transform only.  A wave drops to priority 0 while it MOVES data and
-// waits for it -- the stores, the wait and the loads of a transpose through LDS here; in the 4-element shapes also the
+// Issue priority by phase (TFHE_PHASE_PRIORITY).  A wave drops to priority 0 while it MOVES data and waits for it -- the
+// stores, the wait and the loads of a transpose through LDS here; in the shapes with 8 ring coefficients per lane also the
 // multiply-accumulate with its key loads and spectrum reads (pbs_wave.h) -- and runs its register passes, the digit chain
 // and everything else at priority 2: of the waves of a SIMD the one that has arithmetic to issue goes first.
-// Measured per shape (blind rotation of 4,096, ms; profiles/r04_kernel_ab.txt section 11):
-//   8 elements per lane: transposes low: cfg2's team 28.74 -> 27.95 (aligned 32.23 -> 31.92), cfg1's pair kernel 9.56 -> 9.28;
-//                        the multiply-accumulate low as well: worse (28.6) -- there it stays at 2;
-//   4 elements per lane: transposes low alone: cfg3 level, cfg5 +1 %; multiply-accumulate low alone: -1.3 % / -0.4 %;
-//                        BOTH: cfg3 50.16 -> 49.34, cfg5 169.2 -> 164.4.
+// Measured per shape and field (blind rotation of 4,096, ms; profiles/r04_kernel_ab.txt section 11):
+//   16 coefficients per lane (N = 1024; the pair kernel): transposes low: complex transform cfg2 28.74 -> 27.95 (aligned
+//      32.23 -> 31.92), cfg1's pair kernel 9.56 -> 9.28, fp64-p42 at cfg2 52.65 -> 50.6, Goldilocks 131.6 -> 130.1; the
+//      multiply-accumulate low as well: worse or level (28.6; 50.7; 131.4) -- there it stays at 2;
+//    8 coefficients per lane (N = 512, N = 2048): transposes low alone: cfg3 level, cfg5 +1 %, fp64-p49 at cfg3 -1.2 %,
+//      Goldilocks level; multiply-accumulate low alone: -1.3 % / -0.4 %; BOTH: cfg3 50.16 -> 49.34, cfg5 169.2 -> 164.4,
+//      fp64-p49 67.75 -> 65.45, Goldilocks 221.0 -> 205.0.
 // (Raising the priority INSIDE the transposes, the operand read and the final update low too, and fixed different priorities
 // per wave slot: level or worse.)
 #ifndef TFHE_PHASE_PRIORITY
@@ -493,11 +495,11 @@ __device__ __forceinline__ void swap_transpose(Elem (&x)[E], int lane) {
 #endif
 template <class Elem, int E>
 constexpr bool transpose_lowers_priority() {
-  return TFHE_PHASE_PRIORITY && sizeof(Elem) == 16 && (E == 8 || E == 4);
+  return TFHE_PHASE_PRIORITY != 0;
 }
 template <class Elem, int E>
-constexpr bool mac_lowers_priority() {
-  return TFHE_PHASE_PRIORITY && sizeof(Elem) == 16 && E == 4;
+constexpr bool mac_lowers_priority() {  // 8 ring coefficients per lane: 4 complex elements or 8 field elements
+  return TFHE_PHASE_PRIORITY && E * (int)sizeof(Elem) == 64;
 }
 
 template <class F, int LOGN, int G, int LO_FROM, int LO_TO, bool SKIP_LEAD = false, int NS, class Ctx>
