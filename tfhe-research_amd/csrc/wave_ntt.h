@@ -477,10 +477,11 @@ __device__ __forceinline__ void swap_transpose(Elem (&x)[E], int lane) {
 }
 #endif
 
-// Issue priority by phase (TFHE_PHASE_PRIORITY).  A wave drops to priority 0 while it MOVES data and waits for it -- the
-// stores, the wait and the loads of a transpose through LDS here; in the shapes with 8 ring coefficients per lane also the
-// multiply-accumulate with its key loads and spectrum reads (pbs_wave.h) -- and runs its register passes, the digit chain
-// and everything else at priority 2: of the waves of a SIMD the one that has arithmetic to issue goes first.
+// Issue priority by phase (TFHE_PHASE_PRIORITY).  A wave drops to priority 0 while it MOVES data -- while it issues the
+// stores and the loads of a transpose through LDS here (the s_waitcnt for the loaded registers comes later, where a wave
+// issues nothing anyway); in the shapes with 8 ring coefficients per lane also for the multiply-accumulate with its key
+// loads and spectrum reads (pbs_wave.h) -- and runs its register passes, the digit chain and everything else at priority
+// 2: of the waves of a SIMD the one that has arithmetic to issue goes first.
 // Measured per shape and field (blind rotation of 4,096, ms; profiles/r04_kernel_ab.txt section 11):
 //   16 coefficients per lane (N = 1024; the pair kernel): transposes low: complex transform cfg2 28.74 -> 27.95 (aligned
 //      32.23 -> 31.92), cfg1's pair kernel 9.56 -> 9.28, fp64-p42 at cfg2 52.65 -> 50.6, Goldilocks 131.6 -> 130.1; the
