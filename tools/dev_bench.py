@@ -11,7 +11,9 @@ from oracle import oracle as orc
 orc.set_poly_mul_mode(1)
 which = sys.argv[1]
 BACKEND = getattr(m, os.environ.get('DEV_BACKEND', 'BACKEND_FP64'))
-cfg = {"cfg1": (1, 9, 500, (8, 2), 4096), "cfg2": (1, 10, 630, (7, 3), 4096), "cfg3": (2, 9, 722, (4, 6), 4096), "cfg5": (2, 11, 630, (8, 4), 1024)}[which]
+cfg = {"cfg1": (1, 9, 500, (8, 2), 4096), "cfg2": (1, 10, 630, (7, 3), 4096), "cfg3": (2, 9, 722, (4, 6), 4096), "cfg5": (2, 11, 630, (8, 4), 1024),
+       # shapes outside BASELINE (the other instantiations of the kernels): N = 1024 with k = 2, N = 2048 with k = 1
+       "k2n1024": (2, 10, 600, (4, 7), 2048), "k1n2048": (1, 11, 600, (8, 3), 2048)}[which]
 k, logn, n, pbs, batch = cfg
 batch = int(os.environ.get("DEV_BATCH", batch))
 # parity on a short key first
